@@ -1,0 +1,137 @@
+/* vmtl.h — C ABI of libvmtl.so: the MI355X (gfx950) kernels behind the
+ * vision_mtl multi-task dense-prediction training step.
+ *
+ * The reference (kirilllzaitsev/vision_mtl) has no FFI of its own: its "operator
+ * API" for this path is torch.nn.Module.forward + autograd reaching ATen.  Each
+ * entry point below therefore cites the reference call site (file:line, relative
+ * to the reference repo root) whose ATen dispatch it replaces.  INTEGRATION.md
+ * shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory (HBM) unless noted.
+ *  - activations are NHWC fp32, [B][H][W][Cs], Cs = round_up(C,4); channels [C,Cs) are 0.
+ *  - `stream` is a hipStream_t (void*); nothing here allocates, frees or synchronises,
+ *    so every call can be captured into a hipGraph.
+ *  - return 0 on success, <0 on error (never throws): -1 bad argument, -2 launch
+ *    failure, -3 unsupported configuration.
+ */
+#ifndef VMTL_H
+#define VMTL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMTL_ACT_NONE 0
+#define VMTL_ACT_RELU 1
+#define VMTL_ACT_HSWISH 2
+#define VMTL_ACT_HSIGMOID 3
+#define VMTL_ACT_SIGMOID 4
+
+const char* vmtl_version(void);
+
+/* ---- convolution (implicit GEMM on exact-fp32 MFMA) -------------------------------------
+ * replaces nn.Conv2d / nn.ConvTranspose2d at utils/model_utils.py:71,74;
+ * models/mtan_model.py:31-46,105-129,214-216,369; models/basic_model.py:30-41 (SegmentationHead);
+ * utils/model_utils.py:25-34 (smp.Unet decoder + timm pointwise convs). */
+
+/* y[m][n] = act(bias[n] + sum_kk gather(x)[m][kk] * wp[n][kk]).  wp is [Nw][KH*KW*Cs] (see
+ * vmtl_pack_weights).  The same call with the tap-flipped packing and pad' = K-1-pad is the
+ * data gradient of a stride-1 conv.  shuffle=1 scatters rows n=(u*2+v)*Cout+co to output pixel
+ * (2h+u, 2w+v) channel co: ConvTranspose2d(k=2,s=2).  stats (optional) receives per-row-block
+ * column sums / sums of squares, [vmtl_conv2d_stats_rows()][2][ldy], for BatchNorm. */
+int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
+                    int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
+                    int KH, int KW, int stride, int pad, int act, int shuffle, void* stream);
+int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
+
+/* dwp[n][kk] = sum_m dy[m][n] * gather(x)[m][kk]  (packed layout; zeroed inside the call). */
+int vmtl_conv2d_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cs,
+                      int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad, void* stream);
+
+/* depthwise KxK (K in {3,5}, stride in {1,2}); wp is packed [K*K][Cs]. */
+int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B, int H, int W, int Cs, int Ho, int Wo,
+                    int K, int stride, int pad, void* stream);
+int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
+                         int Wo, int K, int stride, int pad, void* stream);
+int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,
+                           int C, int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream);
+
+/* torch parameter layout <-> packed GEMM operand (formula in csrc/pack.hip). */
+int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
+                      long long sr0, long long st, long long sc, int flip, void* stream);
+int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
+                        long long sr1, long long sr0, long long st, long long sc, int flip, void* stream);
+
+/* ---- BatchNorm2d (+ activation, gate multiply, residual add) -----------------------------
+ * replaces nn.BatchNorm2d/ReLU/Sigmoid/mul at utils/model_utils.py:72-76;
+ * models/mtan_model.py:67-81,139-167. */
+int vmtl_reduce_rows(int M); /* partial rows used by the two-stage reductions */
+int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv, float eps,
+                  float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                  float* save_mean, float* save_invstd, void* stream);
+int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int C, int Cs, float eps,
+                       float* save_mean, float* save_invstd, void* stream);
+int vmtl_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, const float* mul, const float* res, float* y, long long M, int C,
+                  int Cs, int act, void* stream);
+int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                const float* beta, const float* mul, float* dmul, float* partial, float* sum_dz,
+                float* sum_dzx, float* dx, int M, int C, int Cs, int act, int training, void* stream);
+/* out[c] = sum_m a[m][c] (mode 0) or a*b (mode 1); reduce_all sums over channels too. */
+int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
+                float* partial, float* out, void* stream);
+
+/* ---- gathers / elementwise ---------------------------------------------------------------
+ * concat2: utils/model_utils.py:46-58; models/mtan_model.py:65,152,229;
+ *          models/cross_stitch_model.py:126-134; smp DecoderBlock (nearest x2 + cat). */
+int vmtl_concat2(const float* a, int Ha, int Wa, int Ca, int Csa, int upa, int oha, int owa,
+                 const float* b, int Hb, int Wb, int Cb, int Csb, int upb, int ohb, int owb, float* y,
+                 int B, int H, int W, int Cd, void* stream);
+int vmtl_concat2_bwd(const float* dy, float* dx, int B, int H, int W, int Cd, int c_off, int Hs, int Ws,
+                     int C, int Cs, int up, int oh, int ow, void* stream);
+/* models/mtan_model.py:49,81,364,388 */
+int vmtl_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int Cs, void* stream);
+int vmtl_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int Cs, void* stream);
+/* models/mtan_model.py:125,143-144 (bilinear x2, align_corners=True) */
+int vmtl_bilinear_up2_fwd(const float* x, float* y, int B, int H, int W, int Cs, void* stream);
+int vmtl_bilinear_up2_bwd(const float* dy, float* dx, int B, int H, int W, int Cs, void* stream);
+/* timm SqueezeExcite pieces (utils/model_utils.py:25-34) */
+int vmtl_spatial_mean(const float* x, float* y, int B, int HW, int Cs, void* stream);
+int vmtl_channel_bcast(const float* x, const float* s, float* y, int B, int HW, int Cs, int mode, void* stream);
+int vmtl_channel_scale_bwd_s(const float* x, const float* dy, float* ds, int B, int HW, int Cs, void* stream);
+/* models/cross_stitch_model.py:32-37 (diagonal of the 2x2 stitch matrix) */
+int vmtl_stitch(const float* x, const float* w, float* y, long long M, int C, int Cs, int wstride, void* stream);
+/* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */
+int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream);
+/* lit_module.py:137-138 (argmax of softmax == argmax of logits) */
+int vmtl_argmax_channels(const float* z, long long* out, int B, int HW, int C, long long sb, long long sc,
+                         long long sp, void* stream);
+int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, void* stream);
+int vmtl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cs, void* stream);
+
+/* ---- losses ------------------------------------------------------------------------------
+ * lit_module.py:31,123 (CrossEntropyLoss); losses.py:14-36 (SILogLoss); lit_module.py:68,112 (MAE). */
+long long vmtl_ce_workspace_bytes(long long P);
+/* element (b,c,hw) of logits / dlogits sits at [b*sb + c*sc + hw*sp] (NCHW: C*HW, HW, 1). */
+int vmtl_ce_fwd(const float* logits, const long long* target, float* lse, float* loss, void* workspace,
+                int B, int HW, int C, long long sb, long long sc, long long sp, void* stream);
+int vmtl_ce_bwd(const float* logits, const long long* target, const float* lse, const float* grad_out,
+                float* dlogits, int B, int HW, int C, long long sb, long long sc, long long sp, void* stream);
+long long vmtl_silog_workspace_bytes(long long P);
+int vmtl_silog_fwd(const float* pred, const float* target, float min_depth, float* loss, float* stats,
+                   void* workspace, long long P, void* stream);
+int vmtl_silog_bwd(const float* pred, const float* target, const float* stats, const float* grad_out,
+                   float min_depth, float* dpred, long long P, void* stream);
+int vmtl_l1_fwd(const float* pred, const float* target, float* loss, void* workspace, long long P, void* stream);
+int vmtl_l1_bwd(const float* pred, const float* target, const float* grad_out, float* dpred, long long P,
+                void* stream);
+
+/* ---- optimizer (training_lit.py:51,87: torch.optim.Adam) ---------------------------------- */
+int vmtl_adam_step(float* p, const float* g, float* m, float* v, const float* step_ptr, float lr, float b1,
+                   float b2, float eps, float weight_decay, float grad_scale, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMTL_H */

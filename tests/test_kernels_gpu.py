@@ -1,0 +1,370 @@
+"""-m gpu: every HIP kernel family against plain PyTorch fp32 on the CPU (forward values and
+all gradients), on shapes that include the odd channel counts of the `basic` decoder
+(540/270/135/67/33), non-power-of-two maps and M/N/K tails.  Tolerance: 1e-4 of the
+reference's max magnitude (BASELINE.json north_star: "within 1e-4 rel fp32")."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, from_dev_nhwc, to_dev_nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from vision_mtl_amd import ops
+
+    return ops
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, K, stride, pad, bias
+    (2, 3, 16, 24, 16, 3, 2, 1, False),     # stem-like, Cin=3 -> Cs=4, stride 2
+    (2, 67, 12, 20, 33, 3, 1, 1, False),    # decoder block 4 conv1 channels
+    (1, 33, 9, 7, 33, 3, 1, 1, True),       # odd map, M tail
+    (2, 151, 8, 8, 67, 3, 1, 1, False),
+    (1, 294, 4, 8, 135, 3, 1, 1, False),
+    (1, 580, 4, 4, 270, 3, 1, 1, False),
+    (1, 1072, 2, 4, 540, 3, 1, 1, False),
+    (3, 33, 16, 16, 19, 3, 1, 1, True),     # segm head
+    (3, 33, 16, 16, 1, 3, 1, 1, True),      # depth head
+    (2, 192, 8, 8, 128, 1, 1, 0, True),     # MTAN attention 1x1
+    (4, 16, 6, 10, 64, 1, 1, 0, False),     # pointwise expand
+    (5, 960, 1, 1, 240, 1, 1, 0, True),     # SE reduce on a (B,1,1,C) map
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, case):
+    ops = _ops()
+    B, Cin, H, W, Cout, K, stride, pad, bias = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    need_dx = stride == 1
+    xr = x.clone().requires_grad_(need_dx)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = to_dev_nhwc(x, dev).requires_grad_(need_dx)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    y, stats = ops.conv2d(xd, wd, bd, stride=stride, pad=pad, want_stats=True)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="conv fwd")
+    # pad channels must be exactly zero
+    assert y[..., Cout:].abs().max().item() == 0.0 if y.shape[-1] > Cout else True
+    # fused column partials == column sums of the output
+    s = stats.sum(0).cpu()
+    yo = yr.detach()
+    assert_close(s[0, :Cout], yo.sum((0, 2, 3)), tol=2e-4, what="conv stats sum")
+    assert_close(s[1, :Cout], (yo * yo).sum((0, 2, 3)), tol=2e-4, what="conv stats sumsq")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(wd.grad.cpu(), wr.grad, what="conv wgrad")
+    if need_dx:
+        assert_close(from_dev_nhwc(xd.grad, Cin), xr.grad, what="conv dgrad")
+        if xd.grad.shape[-1] > Cin:
+            assert xd.grad[..., Cin:].abs().max().item() == 0.0
+    if bias:
+        assert_close(bd.grad.cpu(), br.grad, what="conv bias grad")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
+def test_conv_transpose2x2(dev, case):
+    ops = _ops()
+    B, Cin, H, W, Cout, bias = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, 2, 2, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    y = ops.conv_transpose2x2(xd, wd, bd)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="convT fwd")
+    if y.shape[-1] > Cout:
+        assert y[..., Cout:].abs().max().item() == 0.0
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, Cin), xr.grad, what="convT dgrad")
+    assert_close(wd.grad.cpu(), wr.grad, what="convT wgrad")
+    if bias:
+        assert_close(bd.grad.cpu(), br.grad, what="convT bias grad")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 12, 20, 3, 1), (2, 64, 12, 20, 3, 2), (2, 72, 9, 11, 5, 2),
+                                  (1, 120, 8, 8, 5, 1), (2, 200, 4, 6, 3, 1), (1, 672, 4, 8, 5, 2)])
+def test_dwconv(dev, case):
+    ops = _ops()
+    B, C, H, W, K, stride = case
+    pad = (K - 1) // 2
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, K, K, generator=g) / K
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad, groups=C)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    y = ops.dwconv(xd, wd, stride=stride, pad=pad)
+    assert_close(from_dev_nhwc(y, C), yr.detach(), what="dwconv fwd")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, what="dwconv dgrad")
+    assert_close(wd.grad.cpu(), wr.grad, what="dwconv wgrad")
+
+
+ACTS = {"none": lambda t: t, "relu": F.relu, "hardswish": F.hardswish, "hardsigmoid": F.hardsigmoid,
+        "sigmoid": torch.sigmoid}
+
+
+@pytest.mark.parametrize("act", list(ACTS))
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(4, 33, 9, 13), (2, 128, 8, 8), (3, 1072, 2, 3)])
+def test_bn_act(dev, act, training, shape):
+    ops = _ops()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    use_mul = act == "sigmoid"       # MTAN gate
+    use_res = act == "none"          # inverted-residual skip
+    mul = torch.randn(B, C, H, W, generator=g) if use_mul else None
+    res = torch.randn(B, C, H, W, generator=g) if use_res else None
+
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rmr, rvr = rm.clone(), rv.clone()
+    mulr = mul.clone().requires_grad_(True) if use_mul else None
+    resr = res.clone().requires_grad_(True) if use_res else None
+    yr = ACTS[act](F.batch_norm(xr, rmr, rvr, gr, br, training=training, momentum=0.1, eps=1e-5))
+    if use_mul:
+        yr = mulr * yr
+    if use_res:
+        yr = yr + resr
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    gd, bd = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    muld = to_dev_nhwc(mul, dev).requires_grad_(True) if use_mul else None
+    resd = to_dev_nhwc(res, dev).requires_grad_(True) if use_res else None
+    y = ops.bn_act(xd, gd, bd, rmd, rvd, nbt, C, training, 0.1, 1e-5, ops.ACT_CODES[act], mul=muld, res=resd)
+    assert_close(from_dev_nhwc(y, C), yr.detach(), what="bn fwd")
+    if y.shape[-1] > C and not use_res:
+        assert y[..., C:].abs().max().item() == 0.0
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=2e-4, what="bn dx")
+    assert_close(gd.grad.cpu(), gr.grad, tol=2e-4, what="bn dgamma")
+    assert_close(bd.grad.cpu(), br.grad, tol=2e-4, what="bn dbeta")
+    if use_mul:
+        assert_close(from_dev_nhwc(muld.grad, C), mulr.grad, what="gate dmul")
+    if use_res:
+        assert_close(from_dev_nhwc(resd.grad, C), resr.grad, what="residual grad")
+    if training:
+        assert_close(rmd.cpu(), rmr, what="running_mean")
+        assert_close(rvd.cpu(), rvr, what="running_var")
+        assert int(nbt.item()) == 1
+
+
+def test_plain_activation(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 30, 5, 7, generator=g) * 3
+    for act in ["relu", "hardswish", "hardsigmoid"]:
+        xr = x.clone().requires_grad_(True)
+        yr = ACTS[act](xr)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        xd = to_dev_nhwc(x, dev).requires_grad_(True)
+        y = ops.activation(xd, ops.ACT_CODES[act], 30)
+        assert_close(from_dev_nhwc(y, 30), yr.detach(), what=act)
+        y.backward(to_dev_nhwc(gy, dev))
+        assert_close(from_dev_nhwc(xd.grad, 30), xr.grad, what=act + " grad")
+
+
+def test_concat_up_pad(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    # smp decoder block: cat[nearest2(x), skip]
+    a, b = torch.randn(2, 135, 4, 6, generator=g), torch.randn(2, 24, 8, 12, generator=g)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.cat([F.interpolate(ar, scale_factor=2, mode="nearest"), br], 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    ad, bd = to_dev_nhwc(a, dev).requires_grad_(True), to_dev_nhwc(b, dev).requires_grad_(True)
+    y = ops.concat2(ad, 135, bd, 24, up_a=2)
+    assert_close(from_dev_nhwc(y, 159), yr.detach(), what="concat up fwd")
+    assert y[..., 159:].abs().max().item() == 0.0
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(ad.grad, 135), ar.grad, what="concat up grad a")
+    assert_close(from_dev_nhwc(bd.grad, 24), br.grad, what="concat grad b")
+    # reference utils/model_utils.py:46-58: zero-pad x1 into x2's canvas (odd differences), cat[x2, x1]
+    x1, x2 = torch.randn(2, 10, 5, 4, generator=g), torch.randn(2, 7, 8, 9, generator=g)
+    x1r, x2r = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    dY, dX = 3, 5
+    yr = torch.cat([x2r, F.pad(x1r, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])], 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    x1d, x2d = to_dev_nhwc(x1, dev).requires_grad_(True), to_dev_nhwc(x2, dev).requires_grad_(True)
+    y = ops.concat2(x2d, 7, x1d, 10, out_hw=(8, 9), off_b=(dY // 2, dX // 2))
+    assert_close(from_dev_nhwc(y, 17), yr.detach(), what="pad concat fwd")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(x1d.grad, 10), x1r.grad, what="pad concat grad x1")
+    assert_close(from_dev_nhwc(x2d.grad, 7), x2r.grad, what="pad concat grad x2")
+
+
+def test_maxpool_bilinear(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    x = F.relu(torch.randn(2, 20, 8, 12, generator=g))  # many exact ties at 0, as after ReLU
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    y = ops.maxpool2(xd)
+    assert torch.equal(from_dev_nhwc(y, 20), yr.detach())
+    y.backward(to_dev_nhwc(gy, dev))
+    assert torch.equal(from_dev_nhwc(xd.grad, 20), xr.grad)
+    for shape in [(2, 12, 5, 7), (1, 128, 16, 16), (2, 4, 1, 3)]:
+        x = torch.randn(*shape, generator=g)
+        xr = x.clone().requires_grad_(True)
+        yr = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        xd = to_dev_nhwc(x, dev).requires_grad_(True)
+        y = ops.bilinear_up2(xd)
+        assert_close(from_dev_nhwc(y, shape[1]), yr.detach(), tol=1e-5, what="bilinear fwd")
+        y.backward(to_dev_nhwc(gy, dev))
+        assert_close(from_dev_nhwc(xd.grad, shape[1]), xr.grad, tol=1e-5, what="bilinear bwd")
+
+
+def test_squeeze_excite_pieces(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(3, 72, 6, 10, generator=g)
+    s = torch.rand(3, 72, 1, 1, generator=g)
+    xr, sr = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    yr = xr * sr + xr.mean((2, 3), keepdim=True)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd, sd = to_dev_nhwc(x, dev).requires_grad_(True), to_dev_nhwc(s, dev).requires_grad_(True)
+    m = ops.spatial_mean(xd)
+    y = ops.channel_scale(xd, sd)
+    assert_close(from_dev_nhwc(m, 72), x.mean((2, 3), keepdim=True), what="spatial mean")
+    assert_close(from_dev_nhwc(y, 72), (x * s), what="channel scale")
+    gyd = to_dev_nhwc(gy, dev)
+    torch.autograd.backward([y, m], [gyd, gyd.sum((1, 2), keepdim=True)])
+    assert_close(from_dev_nhwc(xd.grad, 72), xr.grad, what="se dx")
+    assert_close(from_dev_nhwc(sd.grad, 72), sr.grad, what="se ds")
+
+
+@pytest.mark.parametrize("channel_wise", [True, False])
+def test_stitch(dev, channel_wise):
+    ops = _ops()
+    g = torch.Generator().manual_seed(19)
+    T, B, C, H, W = 2, 3, 22, 5, 6
+    w = torch.rand(T, T, C, generator=g) if channel_wise else torch.rand(T, T, generator=g)
+    x = torch.randn(T, B, C, H, W, generator=g)
+    wr, xr = w.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    eq = "aac,abcij->abcij" if channel_wise else "aa,abcij->abcij"
+    yr = torch.einsum(eq, wr, xr)  # reference models/cross_stitch_model.py:34,36
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    wd = w.to(dev).requires_grad_(True)
+    xs = [to_dev_nhwc(x[a], dev).requires_grad_(True) for a in range(T)]
+    ys = [ops.stitch(xs[a], wd, a, C) for a in range(T)]
+    torch.autograd.backward(ys, [to_dev_nhwc(gy[a], dev) for a in range(T)])
+    for a in range(T):
+        assert_close(from_dev_nhwc(ys[a], C), yr[a].detach(), what="stitch fwd")
+        assert_close(from_dev_nhwc(xs[a].grad, C), xr.grad[a], what="stitch dx")
+    assert_close(wd.grad.cpu(), wr.grad, what="stitch dw")
+    off = wd.grad.cpu()[0, 1]
+    assert float(off.abs().max()) == 0.0  # off-diagonal weights receive exactly zero gradient
+
+
+@pytest.mark.parametrize("C", [19, 14, 5])
+def test_cross_entropy(dev, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    B, H, W = 3, 17, 29
+    z = torch.randn(B, C, H, W, generator=g) * 3
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    zr = z.clone().requires_grad_(True)
+    lr = F.cross_entropy(zr, t)
+    (lr * 1.7).backward()
+    zd = z.to(dev).requires_grad_(True)
+    l = ops.cross_entropy(zd, t.to(dev))
+    (l * 1.7).backward()
+    assert abs(l.item() - lr.item()) <= 1e-5 * abs(lr.item())
+    assert_close(zd.grad.cpu(), zr.grad, tol=1e-5, what="CE grad")
+    assert torch.equal(ops.argmax_channels(zd).cpu(), z.argmax(1))
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_silog_l1_sigmoid(dev, masked):
+    ops = _ops()
+    g = torch.Generator().manual_seed(29)
+    B, H, W = 2, 16, 24
+    zl = torch.randn(B, 1, H, W, generator=g)
+    t = 0.002 + 0.498 * torch.rand(B, H, W, 1, generator=g)
+    if masked:
+        t[torch.rand(B, H, W, 1, generator=g) < 0.1] = 0.0
+    zr = zl.clone().requires_grad_(True)
+    pr = torch.sigmoid(zr).permute(0, 2, 3, 1)
+    m = t > 1e-3
+    gg = torch.log(pr[m]) - torch.log(t[m])
+    lr = 10 * torch.sqrt(torch.var(gg) + 0.15 * torch.mean(gg) ** 2)   # reference losses.py:29-36
+    lr.backward()
+    zd = zl.to(dev).requires_grad_(True)
+    pd = ops.sigmoid(zd).permute(0, 2, 3, 1)
+    l = ops.silog(pd, t.to(dev))
+    l.backward()
+    assert abs(l.item() - lr.item()) <= 1e-5 * abs(lr.item())
+    assert_close(zd.grad.cpu(), zr.grad, tol=1e-4, what="silog grad")
+    zr.grad = None
+    zd.grad = None
+    l1r = (torch.sigmoid(zr).permute(0, 2, 3, 1) - t).abs().mean()
+    l1r.backward()
+    l1 = ops.l1_loss(ops.sigmoid(zd).permute(0, 2, 3, 1), t.to(dev))
+    l1.backward()
+    assert abs(l1.item() - l1r.item()) <= 1e-5 * abs(l1r.item())
+    assert_close(zd.grad.cpu(), zr.grad, tol=1e-4, what="l1 grad")
+
+
+def test_layout_roundtrip_and_adam(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 8, 12, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.to_nhwc(xd)
+    assert torch.equal(from_dev_nhwc(y, 3), x) and y.shape[-1] == 4
+    back = ops.to_nchw(y, 3)
+    assert torch.equal(back.cpu(), x)
+    back.backward(torch.ones_like(back))
+    assert torch.equal(xd.grad.cpu(), torch.ones_like(x))
+    # fused Adam == torch.optim.Adam over 3 steps
+    p = torch.randn(1000, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=5e-3)
+    pd, m, v = p.to(dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    step = torch.zeros(1, device=dev)
+    for i in range(3):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        step += 1
+        ops.adam_step(pd, gr.to(dev), m, v, step, 5e-3)
+    assert_close(pd.cpu(), pr.detach(), tol=1e-6, what="adam")

@@ -1,0 +1,305 @@
+// BatchNorm2d (train: batch statistics; eval: running statistics) fused with the
+// activation that follows it, an optional elementwise gate operand (MTAN's
+// `conv2_shared * sigmoid(bn2(..))`) and an optional residual add (MobileNetV3
+// inverted-residual skip).  NHWC fp32, HBM-bound, 16-byte accesses.
+//
+// Replaces torch.nn.BatchNorm2d + ReLU/Hardswish/Sigmoid + mul/add as invoked at
+//   reference vision_mtl/utils/model_utils.py:72-76 (DoubleConv),
+//   reference vision_mtl/models/mtan_model.py:67-81,139-167 (attention modules),
+//   smp Conv2dReLU / timm BatchNormAct2d (reference vision_mtl/utils/model_utils.py:25-34).
+//
+// Per-channel reductions are two-stage and deterministic: stage 1 writes one
+// partial row per workgroup ([nblk][K][Cs]); the finalize kernels sum the rows in
+// fp64 in a fixed order.
+#include "common.h"
+
+#include "reduce.h"
+
+extern "C" int vmtl_reduce_rows(int M) { return red_blocks(M); }
+
+// ---------------------------------------------------------------- statistics
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const float* __restrict__ x, int M, int Cs,
+                                                               float* partial) {
+  const int CQ = Cs >> 2;
+  column_reduce<2>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * Cs + (size_t)q * 4);
+    acc[0] += v;
+    acc[1] += v * v;
+  });
+}
+
+// mean / invstd from the partial rows; optionally updates running stats the way
+// torch does (momentum, unbiased variance).  save_mean / save_invstd are [Cs].
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, int Cs, float eps,
+                                   float momentum, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
+  if (c >= Cs) return;
+  if (c >= C) {
+    save_mean[c] = 0.f;
+    save_invstd[c] = 0.f;
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)partial[((size_t)b * 2 + 0) * Cs + c];
+    s2 += (double)partial[((size_t)b * 2 + 1) * Cs + c];
+  }
+  const double mean = s1 / M;
+  double var = s2 / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+// eval mode: derive mean / invstd from the running buffers
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     int C, int Cs, float eps, float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cs) return;
+  save_mean[c] = c < C ? running_mean[c] : 0.f;
+  save_invstd[c] = c < C ? 1.f / sqrtf(running_var[c] + eps) : 0.f;
+}
+
+extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv, float eps,
+                             float momentum, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float* save_mean, float* save_invstd, void* stream) {
+  if (!partial || !save_mean || !save_invstd || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = nblk_from_conv;
+  if (nblk <= 0) {  // partial rows not produced by the conv epilogue: sweep x here
+    if (!x) return VMTL_ERR_ARG;
+    nblk = red_blocks(M);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, M, Cs, partial);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, st, partial, nblk, M, C, Cs, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int C, int Cs, float eps,
+                                  float* save_mean, float* save_invstd, void* stream) {
+  if (!running_mean || !running_var || !save_mean || !save_invstd || C <= 0 || C > Cs) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
+                     running_var, C, Cs, eps, save_mean, save_invstd);
+  return vmtl_check_launch();
+}
+
+// ---------------------------------------------------------------- apply
+// y = act(gamma * (x - mean) * invstd + beta) [* mul] [+ res];  pad channels -> 0.
+// gamma/beta may be null (plain activation of x when mean/invstd are null too).
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mul,
+                                                       const float* __restrict__ res, float* __restrict__ y,
+                                                       long long total4, int C, int Cs, int act) {
+  const int CQ = Cs >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % CQ);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = q * 4 + e;
+      float z = v[e];
+      if (c < C) {
+        if (mean != nullptr) {
+          const float sc = (gamma ? gamma[c] : 1.f) * invstd[c];
+          const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+          z = z * sc + sh;
+        }
+        o[e] = act_fwd(z, act);
+      } else {
+        o[e] = 0.f;
+      }
+    }
+    if (mul != nullptr) o *= reinterpret_cast<const f32x4*>(mul)[i];
+    if (res != nullptr) o += reinterpret_cast<const f32x4*>(res)[i];
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
+static inline int ew_blocks(long long total, int per_block) {
+  long long nb = cdivll(total, per_block);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int vmtl_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, const float* mul, const float* res, float* y, long long M, int C,
+                             int Cs, int act, void* stream) {
+  if (!x || !y || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  if ((mean == nullptr) != (invstd == nullptr)) return VMTL_ERR_ARG;
+  const long long total4 = M * (Cs >> 2);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean,
+                     invstd, gamma, beta, mul, res, y, total4, C, Cs, act);
+  return vmtl_check_launch();
+}
+
+// ---------------------------------------------------------------- backward
+// stage 1: partial sums of dz and dz*xhat per channel (dz = dL/d(pre-activation));
+// also emits dmul = dy * act(z) when a gate operand was used.
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mul, float* __restrict__ dmul, int M, int C, int Cs, int act, float* partial) {
+  const int CQ = Cs >> 2;
+  column_reduce<2>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
+    const size_t off = (size_t)r * Cs + (size_t)q * 4;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+    f32x4 mv = {1.f, 1.f, 1.f, 1.f};
+    if (mul != nullptr) mv = *reinterpret_cast<const f32x4*>(mul + off);
+    f32x4 dm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = q * 4 + e;
+      if (c < C) {
+        float xh = xv[e], z = xv[e];
+        if (mean != nullptr) {
+          xh = (xv[e] - mean[c]) * invstd[c];
+          z = (gamma ? gamma[c] : 1.f) * xh + (beta ? beta[c] : 0.f);
+        }
+        if (mul != nullptr) dm[e] = g[e] * act_fwd(z, act);
+        const float dz = g[e] * mv[e] * act_grad(z, act);
+        acc[0][e] += dz;
+        acc[1][e] += dz * xh;
+      }
+    }
+    if (dmul != nullptr) *reinterpret_cast<f32x4*>(dmul + off) = dm;
+  });
+}
+
+// sums the partial rows: dbeta[c] = sum dz, dgamma[c] = sum dz*xhat  (fp64, fixed order)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int Cs, float* sum_dz,
+                                       float* sum_dzx) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cs) return;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int b = 0; b < nblk; ++b) {
+      s1 += (double)partial[((size_t)b * 2 + 0) * Cs + c];
+      s2 += (double)partial[((size_t)b * 2 + 1) * Cs + c];
+    }
+  sum_dz[c] = (float)s1;
+  sum_dzx[c] = (float)s2;
+}
+
+// stage 2: dx.  train: gamma*invstd*(dz - sum_dz/M - xhat*sum_dzx/M); eval (or no BN): scale*dz.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mul, const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx,
+    float* __restrict__ dx, long long total4, int M, int C, int Cs, int act, int training) {
+  const int CQ = Cs >> 2;
+  const float invM = 1.f / (float)M;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % CQ);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    f32x4 mv = {1.f, 1.f, 1.f, 1.f};
+    if (mul != nullptr) mv = reinterpret_cast<const f32x4*>(mul)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = q * 4 + e;
+      float r = 0.f;
+      if (c < C) {
+        if (mean != nullptr) {
+          const float is = invstd[c], gm = gamma ? gamma[c] : 1.f;
+          const float xh = (xv[e] - mean[c]) * is;
+          const float z = gm * xh + (beta ? beta[c] : 0.f);
+          const float dz = g[e] * mv[e] * act_grad(z, act);
+          r = training ? gm * is * (dz - sum_dz[c] * invM - xh * sum_dzx[c] * invM) : gm * is * dz;
+        } else {
+          r = g[e] * mv[e] * act_grad(xv[e], act);
+        }
+      }
+      o[e] = r;
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = o;
+  }
+}
+
+// One call = reduce + finalize + apply.  `partial` needs vmtl_reduce_rows(M)*2*Cs floats.
+// sum_dz / sum_dzx ([Cs]) are the bias / weight gradients of the BatchNorm.
+extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, const float* mul, float* dmul, float* partial,
+                           float* sum_dz, float* sum_dzx, float* dx, int M, int C, int Cs, int act, int training,
+                           void* stream) {
+  if (!x || !dy || !dx || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  if ((mean == nullptr) != (invstd == nullptr)) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bool need_sums = mean != nullptr;  // a bare activation has no per-channel sums
+  if (need_sums || dmul != nullptr) {
+    if (!partial || (need_sums && (!sum_dz || !sum_dzx))) return VMTL_ERR_ARG;
+    const int nblk = red_blocks(M);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, mean, invstd, gamma, beta,
+                       mul, dmul, M, C, Cs, act, partial);
+    if (need_sums)
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, st, partial, nblk, C, Cs, sum_dz,
+                         sum_dzx);
+  }
+  const long long total4 = (long long)M * (Cs >> 2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, st, x, dy, mean, invstd, gamma,
+                     beta, mul, sum_dz, sum_dzx, dx, total4, M, C, Cs, act, training);
+  return vmtl_check_launch();
+}
+
+// ---------------------------------------------------------------- generic column sums
+// out[k][c] = sum_m f_k(a[m][c], b[m][c]);  mode 0: (a) -> bias gradient, mode 1: (a*b) -> stitch/scale gradient
+__global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ b, int M, int Cs, int mode,
+                                                             float* partial) {
+  const int CQ = Cs >> 2;
+  column_reduce<1>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
+    const size_t off = (size_t)r * Cs + (size_t)q * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a + off);
+    if (mode == 1) v *= *reinterpret_cast<const f32x4*>(b + off);
+    acc[0] += v;
+  });
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int Cs, int reduce_all,
+                                       float* out) {
+  if (reduce_all) {  // a single scalar: sum over channels too (layer-wise stitch weight gradient)
+    __shared__ double red[128];
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+      for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * Cs + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 64; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+    return;
+  }
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * Cs + c];
+  out[c] = (float)s;
+}
+
+extern "C" int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
+                           float* partial, float* out, void* stream) {
+  if (!a || !partial || !out || M <= 0 || C <= 0 || C > Cs || (Cs & 3) || (mode == 1 && !b)) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = red_blocks(M);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, a, b, M, Cs, mode, partial);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(reduce_all ? 1 : cdiv(C, 128)), dim3(128), 0, st, partial, nblk, C,
+                     Cs, reduce_all, out);
+  return vmtl_check_launch();
+}

@@ -1,0 +1,152 @@
+// Depthwise KxK convolution (k in {3,5}, stride in {1,2}), NHWC fp32: forward, data
+// gradient and weight gradient.  K = 9 / 25 per output, so this is VALU + L1/L2-reuse
+// work (not MFMA): one thread owns 4 channels of one pixel and walks the taps; all
+// accesses are 16-byte and coalesced along the channel axis.
+//
+// Replaces the depthwise ATen convs of timm MobileNetV3 DepthwiseSeparable / InvertedResidual
+// blocks reached from reference vision_mtl/utils/model_utils.py:25-34 (smp.Unet encoder) [3P].
+//
+// Weights are consumed in packed [tap][Cs] form (see pack.hip).
+#include "reduce.h"
+
+#define DW_MAX_TAPS 25
+
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                         float* __restrict__ y, int B, int H, int W, int Cs, int Ho,
+                                                         int Wo, int K, int stride, int pad, long long total4) {
+  const int CQ = Cs >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % CQ);
+    const long long pix = i / CQ;
+    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int dh = 0; dh < K; ++dh) {
+      const int h = ho * stride - pad + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int dw = 0; dw < K; ++dw) {
+        const int w = wo * stride - pad + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + h) * W + w) * Cs + (size_t)q * 4);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)(dh * K + dw) * Cs + (size_t)q * 4);
+        acc += xv * wv;
+      }
+    }
+    reinterpret_cast<f32x4*>(y)[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __restrict__ dy,
+                                                              const float* __restrict__ wp, float* __restrict__ dx,
+                                                              int B, int H, int W, int Cs, int Ho, int Wo, int K,
+                                                              int stride, int pad, long long total4) {
+  const int CQ = Cs >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % CQ);
+    const long long pix = i / CQ;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int dh = 0; dh < K; ++dh) {
+      const int hn = h + pad - dh;
+      if (hn < 0 || hn % stride) continue;
+      const int ho = hn / stride;
+      if (ho >= Ho) continue;
+      for (int dw = 0; dw < K; ++dw) {
+        const int wn = w + pad - dw;
+        if (wn < 0 || wn % stride) continue;
+        const int wo = wn / stride;
+        if (wo >= Wo) continue;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((size_t)(b * Ho + ho) * Wo + wo) * Cs + (size_t)q * 4);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)(dh * K + dw) * Cs + (size_t)q * 4);
+        acc += g * wv;
+      }
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = acc;
+  }
+}
+
+// weight gradient: per-workgroup partial [nblk][K*K][Cs] over output pixels, then a fixed-order sum
+template <int KK>
+__global__ __launch_bounds__(RED_THREADS) void dwconv_bwd_w_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ dy, int H, int W, int Cs,
+                                                                   int Ho, int Wo, int K, int stride, int pad, int M,
+                                                                   float* partial) {
+  const int CQ = Cs >> 2;
+  column_reduce<KK>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
+    const int wo = r % Wo, ho = (r / Wo) % Ho, b = r / (Wo * Ho);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)r * Cs + (size_t)q * 4);
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const int dh = t / K, dw = t - dh * K;
+      const int h = ho * stride - pad + dh, w = wo * stride - pad + dw;
+      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+        acc[t] += g * *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + h) * W + w) * Cs + (size_t)q * 4);
+    }
+  });
+}
+
+// dw[c][tap] (torch layout (C,1,K,K)) = sum over partial rows, fp64
+__global__ void dwconv_bwd_w_finalize_kernel(const float* __restrict__ partial, int nblk, int KK, int C, int Cs,
+                                             float* dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * KK) return;
+  const int c = i / KK, t = i - c * KK;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[((size_t)b * KK + t) * Cs + c];
+  dw[i] = (float)s;
+}
+
+static inline int dw_grid(long long total4) {
+  long long nb = cdivll(total4, 256);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+static int dw_check(int B, int H, int W, int Cs, int Ho, int Wo, int K, int stride, int pad) {
+  if (B <= 0 || H <= 0 || W <= 0 || (Cs & 3) || Cs <= 0) return VMTL_ERR_ARG;
+  if ((K != 3 && K != 5) || (stride != 1 && stride != 2) || pad < 0) return VMTL_ERR_ARG;
+  if ((H + 2 * pad - K) / stride + 1 != Ho || (W + 2 * pad - K) / stride + 1 != Wo) return VMTL_ERR_ARG;
+  if ((long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
+  return VMTL_OK;
+}
+
+extern "C" int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B, int H, int W, int Cs, int Ho, int Wo,
+                               int K, int stride, int pad, void* stream) {
+  if (!x || !wp || !y) return VMTL_ERR_ARG;
+  if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
+  const long long total4 = (long long)B * Ho * Wo * (Cs >> 2);
+  hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(dw_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, wp, y, B, H, W,
+                     Cs, Ho, Wo, K, stride, pad, total4);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
+                                    int Wo, int K, int stride, int pad, void* stream) {
+  if (!dy || !wp || !dx) return VMTL_ERR_ARG;
+  if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
+  const long long total4 = (long long)B * H * W * (Cs >> 2);
+  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(dw_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, wp, dx, B,
+                     H, W, Cs, Ho, Wo, K, stride, pad, total4);
+  return vmtl_check_launch();
+}
+
+// partial: vmtl_reduce_rows(B*Ho*Wo) * K*K * Cs floats.  dw: torch (C,1,K,K) layout.
+extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,
+                                      int C, int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream) {
+  if (!x || !dy || !partial || !dw || C <= 0 || C > Cs) return VMTL_ERR_ARG;
+  if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int M = B * Ho * Wo;
+  const int nblk = red_blocks(M);
+  if (K == 3)
+    hipLaunchKernelGGL((dwconv_bwd_w_kernel<9>), dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
+                       stride, pad, M, partial);
+  else
+    hipLaunchKernelGGL((dwconv_bwd_w_kernel<25>), dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
+                       stride, pad, M, partial);
+  hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(cdiv(C * K * K, 128)), dim3(128), 0, st, partial, nblk, K * K,
+                     C, Cs, dw);
+  return vmtl_check_launch();
+}

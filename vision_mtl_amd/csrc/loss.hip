@@ -1,0 +1,251 @@
+// Per-pixel losses of the multi-task step, forward and backward.
+//
+//   cross entropy : torch.nn.CrossEntropyLoss() as used at reference lit_module.py:31,123
+//                   (mean over B*H*W, no ignore_index / class weights / smoothing)
+//   SILog         : reference vision_mtl/losses.py:14-36 on already-sigmoided predictions
+//                   (mask = target > min_depth, unbiased variance, 10*sqrt(var + 0.15*mean^2))
+//   L1 / MAE      : the depth metric of reference lit_module.py:68,112 (mean |p - t|)
+//
+// Reductions are two-stage: per-workgroup partials in fp64, summed in a fixed order by a
+// single finalize workgroup, so results are run-to-run reproducible.
+#include "common.h"
+
+#define CE_THREADS 256
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) s += sh[i];
+  return s;
+}
+
+// Element (b, c, hw) of the logits sits at z[b*sb + c*sc + hw*sp]:
+//   NCHW (the reference's layout at the boundary): sb = C*HW, sc = HW, sp = 1  -> every channel
+//   read of a wave is 256 contiguous bytes;  NHWC: sb = HW*ld, sc = 1, sp = ld.
+// One thread per pixel, online max / sum over the (few) channels in registers.
+__global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restrict__ z,
+                                                            const long long* __restrict__ tgt,
+                                                            float* __restrict__ lse, double* __restrict__ partial,
+                                                            int* __restrict__ err, long long P, int HW, int C,
+                                                            long long sb, long long sc, long long sp) {
+  __shared__ double shd[4];
+  double loss = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, hw = i - b * HW;
+    const float* r = z + b * sb + hw * sp;
+    float m = r[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, r[c * sc]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(r[c * sc] - m);
+    const float l = m + logf(s);
+    lse[i] = l;
+    const long long t = tgt[i];
+    if (t < 0 || t >= C) atomicOr(err, 1);  // torch raises on an out-of-range class index
+    else loss += (double)(l - r[t * sc]);
+  }
+  const double bs = block_sum_d(loss, shd);
+  if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+}
+
+__global__ void sum_finalize_kernel(const double* __restrict__ partial, int n, double scale, float* out) {
+  __shared__ double shd[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  const double t = block_sum_d(s, shd);
+  if (threadIdx.x == 0) out[0] = (float)(t * scale);
+}
+
+// dz = (softmax(z) - onehot(y)) * gout / P, written with the same strides as z
+__global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restrict__ z,
+                                                            const long long* __restrict__ tgt,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ gout, float* __restrict__ dz,
+                                                            long long P, int HW, int C, long long sb, long long sc,
+                                                            long long sp) {
+  const float g = gout[0] / (float)P;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, hw = i - b * HW;
+    const long long off = b * sb + hw * sp;
+    const float l = lse[i];
+    const int t = (int)tgt[i];
+    for (int c = 0; c < C; ++c) dz[off + c * sc] = (expf(z[off + c * sc] - l) - (c == t ? 1.f : 0.f)) * g;
+  }
+}
+
+static inline int ce_blocks(long long P) {
+  long long nb = cdivll(P, CE_THREADS);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" long long vmtl_ce_workspace_bytes(long long P) { return ((long long)ce_blocks(P) + 1) * (long long)sizeof(double); }
+
+// workspace: vmtl_ce_workspace_bytes(P) bytes, 8-byte aligned; the last slot holds the int error flag
+// (non-zero after the call = some target outside [0, C)).
+extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* lse, float* loss, void* workspace,
+                           int B, int HW, int C, long long sb, long long sc, long long sp, void* stream) {
+  if (!logits || !target || !lse || !loss || !workspace || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = (long long)B * HW;
+  const int nblk = ce_blocks(P);
+  double* partial = (double*)workspace;
+  int* err = (int*)(partial + nblk);
+  if (hipMemsetAsync(err, 0, sizeof(double), st) != hipSuccess) return VMTL_ERR_LAUNCH;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, lse, partial, err, P, HW, C,
+                     sb, sc, sp);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_ce_bwd(const float* logits, const long long* target, const float* lse, const float* grad_out,
+                           float* dlogits, int B, int HW, int C, long long sb, long long sc, long long sp,
+                           void* stream) {
+  if (!logits || !target || !lse || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
+  const long long P = (long long)B * HW;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target, lse,
+                     grad_out, dlogits, P, HW, C, sb, sc, sp);
+  return vmtl_check_launch();
+}
+
+// ------------------------------------------------------------------ SILog
+#define SL_BLOCKS_MAX 1024
+
+__global__ __launch_bounds__(256) void silog_fwd_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ tgt, float min_depth, long long P,
+                                                        double* __restrict__ partial) {
+  __shared__ double shd[4];
+  double n = 0.0, s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const float t = tgt[i];
+    if (t > min_depth) {
+      const float g = logf(pred[i]) - logf(t);
+      n += 1.0;
+      s1 += (double)g;
+      s2 += (double)g * (double)g;
+    }
+  }
+  const double bn = block_sum_d(n, shd);
+  const double b1 = block_sum_d(s1, shd);
+  const double b2 = block_sum_d(s2, shd);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = bn;
+    partial[blockIdx.x * 3 + 1] = b1;
+    partial[blockIdx.x * 3 + 2] = b2;
+  }
+}
+
+// stats[0] = N, stats[1] = mean(g), stats[2] = Dg ; loss = 10*sqrt(Dg)
+__global__ void silog_finalize_kernel(const double* __restrict__ partial, int nblk, float* loss, float* stats) {
+  __shared__ double shd[4];
+  double n = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+    n += partial[i * 3 + 0];
+    s1 += partial[i * 3 + 1];
+    s2 += partial[i * 3 + 2];
+  }
+  n = block_sum_d(n, shd);
+  s1 = block_sum_d(s1, shd);
+  s2 = block_sum_d(s2, shd);
+  if (threadIdx.x == 0) {
+    const double mu = s1 / n;                          // n == 0 -> NaN, as torch.mean of an empty tensor
+    const double var = (s2 - n * mu * mu) / (n - 1.0); // n == 1 -> NaN (unbiased variance), as torch.var
+    const double dg = var + 0.15 * mu * mu;
+    loss[0] = (float)(10.0 * sqrt(dg));
+    stats[0] = (float)n;
+    stats[1] = (float)mu;
+    stats[2] = (float)dg;
+  }
+}
+
+// dL/dpred_i = gout * (5/sqrt(Dg)) * (2 (g_i - mu)/(N-1) + 0.3 mu / N) / pred_i   on valid pixels, else 0
+__global__ __launch_bounds__(256) void silog_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gout, float min_depth, long long P,
+                                                        float* __restrict__ dpred) {
+  const float n = stats[0], mu = stats[1], dg = stats[2];
+  const float k = gout[0] * 5.f / sqrtf(dg);
+  const float a = 2.f / (n - 1.f), b = 0.3f * mu / n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const float t = tgt[i];
+    float r = 0.f;
+    if (t > min_depth) {
+      const float p = pred[i];
+      const float g = logf(p) - logf(t);
+      r = k * (a * (g - mu) + b) / p;
+    }
+    dpred[i] = r;
+  }
+}
+
+static inline int sl_blocks(long long P) {
+  long long nb = cdivll(P, 1024);
+  if (nb > SL_BLOCKS_MAX) nb = SL_BLOCKS_MAX;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" long long vmtl_silog_workspace_bytes(long long P) { return (long long)sl_blocks(P) * 3 * sizeof(double); }
+
+extern "C" int vmtl_silog_fwd(const float* pred, const float* target, float min_depth, float* loss, float* stats,
+                              void* workspace, long long P, void* stream) {
+  if (!pred || !target || !loss || !stats || !workspace || P <= 0) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = sl_blocks(P);
+  hipLaunchKernelGGL(silog_fwd_kernel, dim3(nblk), dim3(256), 0, st, pred, target, min_depth, P, (double*)workspace);
+  hipLaunchKernelGGL(silog_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, loss, stats);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_silog_bwd(const float* pred, const float* target, const float* stats, const float* grad_out,
+                              float min_depth, float* dpred, long long P, void* stream) {
+  if (!pred || !target || !stats || !grad_out || !dpred || P <= 0) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(silog_bwd_kernel, dim3(sl_blocks(P)), dim3(256), 0, (hipStream_t)stream, pred, target, stats,
+                     grad_out, min_depth, P, dpred);
+  return vmtl_check_launch();
+}
+
+// ------------------------------------------------------------------ L1 (mean absolute error)
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                     long long P, double* __restrict__ partial) {
+  __shared__ double shd[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x)
+    s += (double)fabsf(pred[i] - tgt[i]);
+  const double b = block_sum_d(s, shd);
+  if (threadIdx.x == 0) partial[blockIdx.x] = b;
+}
+
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                     const float* __restrict__ gout, long long P,
+                                                     float* __restrict__ dpred) {
+  const float g = gout[0] / (float)P;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const float d = pred[i] - tgt[i];
+    dpred[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+  }
+}
+
+extern "C" int vmtl_l1_fwd(const float* pred, const float* target, float* loss, void* workspace, long long P,
+                           void* stream) {
+  if (!pred || !target || !loss || !workspace || P <= 0) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = sl_blocks(P);
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblk), dim3(256), 0, st, pred, target, P, (double*)workspace);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, 1.0 / (double)P,
+                     loss);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_l1_bwd(const float* pred, const float* target, const float* grad_out, float* dpred, long long P,
+                           void* stream) {
+  if (!pred || !target || !grad_out || !dpred || P <= 0) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(sl_blocks(P)), dim3(256), 0, (hipStream_t)stream, pred, target, grad_out, P,
+                     dpred);
+  return vmtl_check_launch();
+}

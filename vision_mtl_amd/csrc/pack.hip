@@ -1,0 +1,107 @@
+// Weight (un)packing between the torch parameter layouts the drop-in boundary keeps
+// (Conv2d: (Cout,Cin,KH,KW); ConvTranspose2d: (Cin,Cout,2,2); depthwise: (C,1,K,K))
+// and the [row][tap*Cs + c] matrices the implicit-GEMM kernels contract against,
+// plus the fused Adam update over the flat parameter arena.
+//
+//   packed[(r1*R0 + r0)][t'*Cs + c] = src[r1*sr1 + r0*sr0 + t*st + c*sc],   c < C, else 0
+//   t' = flip ? T-1-t : t
+//
+//   conv fwd   : R1=1 R0=Cout T=KH*KW C=Cin  sr0=Cin*KK st=1 sc=KK        flip=0
+//   conv dgrad : R1=1 R0=Cin  T=KK    C=Cout sr0=KK     st=1 sc=Cin*KK    flip=1
+//   convT fwd  : R1=4 R0=Cout T=1     C=Cin  sr1=1 sr0=4 st=0 sc=Cout*4   flip=0
+//   convT bwd  : R1=1 R0=Cin  T=4     C=Cout sr0=Cout*4 st=1 sc=4         flip=0
+//   depthwise  : R1=1 R0=1    T=KK    C=C    st=1 sc=KK                   flip=0
+//
+// Adam follows torch.optim.Adam (reference vision_mtl/training_lit.py:51,87).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int R1,
+                                                   int R0, int T, int C, int Cs, long long sr1, long long sr0,
+                                                   long long st, long long sc, int flip, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cs);
+    long long rest = i / Cs;
+    const int tp = (int)(rest % T);
+    rest /= T;
+    const int r0 = (int)(rest % R0);
+    const int r1 = (int)(rest / R0);
+    const int t = flip ? T - 1 - tp : tp;
+    dst[i] = c < C ? src[r1 * sr1 + r0 * sr0 + t * st + c * sc] : 0.f;
+  }
+}
+
+// inverse: grad[torch index] = packed[...]; one thread per torch-layout element
+__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ packed, float* __restrict__ grad,
+                                                     int R1, int R0, int T, int C, int Cs, long long sr1,
+                                                     long long sr0, long long st, long long sc, int flip,
+                                                     long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long long rest = i / C;
+    const int t = (int)(rest % T);
+    rest /= T;
+    const int r0 = (int)(rest % R0);
+    const int r1 = (int)(rest / R0);
+    const int tp = flip ? T - 1 - t : t;
+    grad[r1 * sr1 + r0 * sr0 + t * st + c * sc] = packed[((size_t)(r1 * R0 + r0) * T + tp) * Cs + c];
+  }
+}
+
+static inline int pk_grid(long long total) {
+  long long nb = cdivll(total, 256);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
+                                 long long sr0, long long st, long long sc, int flip, void* stream) {
+  if (!src || !dst || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs) return VMTL_ERR_ARG;
+  const long long total = (long long)R1 * R0 * T * Cs;
+  hipLaunchKernelGGL(pack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, R1, R0, T, C, Cs,
+                     sr1, sr0, st, sc, flip, total);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
+                                   long long sr1, long long sr0, long long st, long long sc, int flip, void* stream) {
+  if (!packed || !grad || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs) return VMTL_ERR_ARG;
+  const long long total = (long long)R1 * R0 * T * C;
+  hipLaunchKernelGGL(unpack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, packed, grad, R1, R0, T,
+                     C, Cs, sr1, sr0, st, sc, flip, total);
+  return vmtl_check_launch();
+}
+
+// ------------------------------------------------------------------ fused Adam over a flat arena
+// step_ptr[0] holds the (already incremented) step count as a float so the update can sit in a hipGraph.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ step_ptr, float lr, float b1, float b2,
+                                                   float eps, float wd, float gscale, long long n) {
+  const float step = step_ptr[0];
+  const float bc1 = 1.f - powf(b1, step);
+  const float bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+extern "C" int vmtl_adam_step(float* p, const float* g, float* m, float* v, const float* step_ptr, float lr, float b1,
+                              float b2, float eps, float weight_decay, float grad_scale, long long n, void* stream) {
+  if (!p || !g || !m || !v || !step_ptr || n <= 0) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(adam_kernel, dim3(pk_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step_ptr, lr, b1,
+                     b2, eps, weight_decay, grad_scale, n);
+  return vmtl_check_launch();
+}

@@ -1,0 +1,673 @@
+"""Autograd bindings of the vmtl C ABI (include/vmtl.h).
+
+Everything here is host plumbing: allocate output / workspace tensors with the torch
+allocator, hand raw device pointers + the current HIP stream to libvmtl.so, register
+the matching backward call with autograd.  No arithmetic happens in Python and there
+is no fallback: tensors must live on a GPU and the extension must load.
+
+Internal activation format: contiguous fp32 [B, H, W, Cs] (NHWC) with
+Cs = ceil4(C) and zero padding channels; the logical channel count C travels with
+the calling module.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import lib
+
+ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "hardswish": 2, "hardsigmoid": 3, "sigmoid": 4}
+
+
+def ceil4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the vmtl hot path only runs as HIP kernels on an MI355X "
+            "(there is deliberately no CPU fallback)"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _k(name, **kw):
+    lib().callk(name, stream=_stream(), **kw)
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _reduce_rows(M: int) -> int:
+    return lib().raw("vmtl_reduce_rows")(M)
+
+
+# ----------------------------------------------------------------------------- packing
+def pack(src, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0):
+    dst = _empty((R1 * R0, T * Cs), src)
+    _k("vmtl_pack_weights", src=src, dst=dst, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st, sc=sc, flip=flip)
+    return dst
+
+
+def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0):
+    grad = _empty(shape, packed)
+    _k("vmtl_unpack_weights", packed=packed, grad=grad, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st,
+       sc=sc, flip=flip)
+    return grad
+
+
+def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0):
+    partial = _empty((_reduce_rows(M), Cs), a)
+    out = _empty((1 if reduce_all else C,), a)
+    _k("vmtl_colsum", a=a, b=b, M=M, C=C, Cs=Cs, mode=mode, reduce_all=reduce_all, partial=partial, out=out)
+    return out
+
+
+def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0):
+    _k("vmtl_conv2d_fwd", x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
+       Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act=0, shuffle=shuffle)
+
+
+# ----------------------------------------------------------------------------- conv2d
+class _Conv2d(torch.autograd.Function):
+    """y = conv2d(x, weight) (+ bias); weight stays in torch (Cout, Cin, KH, KW) layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, want_stats):
+        x = _req(x, "x")
+        weight = _req(weight, "weight")
+        B, H, W, Cs = x.shape
+        Cout, Cin, KH, KW = weight.shape
+        if ceil4(Cin) != Cs:
+            raise ValueError(f"conv2d: input has {Cs} storage channels, weight expects Cin={Cin}")
+        KK = KH * KW
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        ldy = ceil4(Cout)
+        wp = pack(weight, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK)
+        y = _empty((B, Ho, Wo, ldy), x)
+        stats = None
+        if want_stats:
+            rows = lib().raw("vmtl_conv2d_stats_rows")(B, Ho, Wo, ldy)
+            stats = _empty((rows, 2, ldy), x)
+        _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Cout, Cout, KH, KW, stride, pad)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, bias is not None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        Cout, Cin, KH, KW = weight.shape
+        KK = KH * KW
+        _, Ho, Wo, ldy = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if stride != 1:
+                raise NotImplementedError("data gradient of a strided dense conv is not on the hot path")
+            wd = pack(weight, 1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, flip=1)
+            dx = _empty((B, H, W, Cs), x)
+            _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad)
+        if ctx.needs_input_grad[1]:
+            dwp = _empty((Cout, KK * Cs), x)
+            _k("vmtl_conv2d_wgrad", x=x, dy=dy, dwp=dwp, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Cout, KH=KH,
+               KW=KW, stride=stride, pad=pad)
+            dw = unpack(dwp, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, None, B * Ho * Wo, Cout, ldy)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False):
+    y, stats = _Conv2d.apply(x, weight, bias, stride, pad, want_stats)
+    return (y, stats) if want_stats else y
+
+
+# ----------------------------------------------------------------------------- ConvTranspose2d(k=2, s=2)
+class _ConvT2x2(torch.autograd.Function):
+    """weight in torch (Cin, Cout, 2, 2) layout; reference models/mtan_model.py:214-216."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _req(x, "x")
+        weight = _req(weight, "weight")
+        B, H, W, Cs = x.shape
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        if tuple(weight.shape[2:]) != (2, 2) or ceil4(Cin) != Cs:
+            raise ValueError("conv_transpose2x2: weight must be (Cin, Cout, 2, 2) matching the input channels")
+        ldy = ceil4(Cout)
+        wp = pack(weight, 4, Cout, 1, Cin, Cs, 1, 4, 0, Cout * 4)
+        y = _empty((B, 2 * H, 2 * W, ldy), x)
+        _conv_launch(x, wp, bias, y, None, B, H, W, Cs, H, W, ldy, 4 * Cout, Cout, 1, 1, 1, 0, shuffle=1)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        ldy = dy.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:  # a 2x2 / stride-2 conv over dy
+            wd = pack(weight, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4)
+            dx = _empty((B, H, W, Cs), x)
+            _conv_launch(dy, wd, None, dx, None, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, Cin, 2, 2, 2, 0)
+        if ctx.needs_input_grad[1]:  # weight gradient of that same conv, with x in the role of its output gradient
+            dwp = _empty((Cin, 4 * ldy), x)
+            _k("vmtl_conv2d_wgrad", x=dy, dy=x, dwp=dwp, B=B, H=2 * H, W=2 * W, Cs=ldy, Ho=H, Wo=W, ldy=Cs, Nw=Cin,
+               KH=2, KW=2, stride=2, pad=0)
+            dw = unpack(dwp, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, None, B * 4 * H * W, Cout, ldy)
+        return dx, dw, db
+
+
+def conv_transpose2x2(x, weight, bias=None):
+    return _ConvT2x2.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------- depthwise conv
+class _DwConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = _req(x, "x")
+        weight = _req(weight, "weight")
+        B, H, W, Cs = x.shape
+        C, one, K, K2 = weight.shape
+        if one != 1 or K != K2 or ceil4(C) != Cs:
+            raise ValueError("dwconv: weight must be (C, 1, K, K) matching the input channels")
+        Ho = (H + 2 * pad - K) // stride + 1
+        Wo = (W + 2 * pad - K) // stride + 1
+        wp = pack(weight, 1, 1, K * K, C, Cs, 0, 0, 1, K * K)
+        y = _empty((B, Ho, Wo, Cs), x)
+        _k("vmtl_dwconv_fwd", x=x, wp=wp, y=y, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
+        ctx.save_for_backward(x, weight, wp)
+        ctx.cfg = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, wp = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        C, _, K, _ = weight.shape
+        _, Ho, Wo, _ = dy.shape
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x.shape, x)
+            _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=dx, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride,
+               pad=pad)
+        if ctx.needs_input_grad[1]:
+            partial = _empty((_reduce_rows(B * Ho * Wo), K * K, Cs), x)
+            dw = _empty(weight.shape, x)
+            _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo,
+               K=K, stride=stride, pad=pad)
+        return dx, dw, None, None
+
+
+def dwconv(x, weight, stride=1, pad=1):
+    return _DwConv.apply(x, weight, stride, pad)
+
+
+# ----------------------------------------------------------------------------- BatchNorm + act (+ gate, + residual)
+class _BNAct(torch.autograd.Function):
+    """y = act(BN(x)) [* mul] [+ res].  gamma/beta None -> plain activation (no normalisation)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, mul, res, stats, C, training, momentum, eps,
+                act):
+        x = _req(x, "x")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        mean = invstd = None
+        if gamma is not None:
+            mean, invstd = _empty((Cs,), x), _empty((Cs,), x)
+            if training:
+                if stats is not None:
+                    partial, nblk = stats, stats.shape[0]
+                else:
+                    partial, nblk = _empty((_reduce_rows(M), 2, Cs), x), 0
+                _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk, eps=eps,
+                   momentum=momentum, running_mean=running_mean, running_var=running_var, num_batches_tracked=nbt,
+                   save_mean=mean, save_invstd=invstd)
+            else:
+                _k("vmtl_bn_eval_stats", running_mean=running_mean, running_var=running_var, C=C, Cs=Cs, eps=eps,
+                   save_mean=mean, save_invstd=invstd)
+        if mul is not None:
+            mul = _req(mul, "mul")
+        if res is not None:
+            res = _req(res, "res")
+        y = _empty(x.shape, x)
+        _k("vmtl_bn_apply", x=x, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=mul, res=res, y=y, M=M, C=C,
+           Cs=Cs, act=act)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, mul)
+        ctx.cfg = (C, training, act, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, mul = ctx.saved_tensors
+        C, training, act, has_res = ctx.cfg
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        need_sums = gamma is not None
+        dmul = _empty(x.shape, x) if (mul is not None and ctx.needs_input_grad[6]) else None
+        partial = sum_dz = sum_dzx = None
+        if need_sums or dmul is not None:
+            partial = _empty((_reduce_rows(M), 2, Cs), x)
+        if need_sums:
+            sum_dz, sum_dzx = _empty((Cs,), x), _empty((Cs,), x)
+        dx = _empty(x.shape, x)
+        _k("vmtl_bn_bwd", x=x, dy=dy, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=mul, dmul=dmul,
+           partial=partial, sum_dz=sum_dz, sum_dzx=sum_dzx, dx=dx, M=M, C=C, Cs=Cs, act=act,
+           training=1 if training else 0)
+        dgamma = sum_dzx[:C] if need_sums else None
+        dbeta = sum_dz[:C] if need_sums else None
+        return (dx, dgamma, dbeta, None, None, None, dmul, dy if has_res else None, None, None, None, None, None,
+                None)
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, nbt, C, training, momentum=0.1, eps=1e-5, act=ACT_NONE,
+           mul=None, res=None, stats=None):
+    return _BNAct.apply(x, gamma, beta, running_mean, running_var, nbt, mul, res, stats, C, training, momentum, eps,
+                        act)
+
+
+def activation(x, act, C, mul=None):
+    """Plain activation (optionally times a gate operand) through the same fused kernel."""
+    return _BNAct.apply(x, None, None, None, None, None, mul, None, None, C, False, 0.0, 0.0, act)
+
+
+# ----------------------------------------------------------------------------- concat / upsample / pad
+class _Concat2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, Ca, Cb, up_a, up_b, H, W, off_a, off_b):
+        a = _req(a, "a")
+        B, Ha, Wa, Csa = a.shape
+        if b is not None:
+            b = _req(b, "b")
+            _, Hb, Wb, Csb = b.shape
+        else:
+            Hb = Wb = Csb = 0
+            Cb = 0
+        Cd = ceil4(Ca + Cb)
+        y = _empty((B, H, W, Cd), a)
+        _k("vmtl_concat2", a=a, Ha=Ha, Wa=Wa, Ca=Ca, Csa=Csa, upa=up_a, oha=off_a[0], owa=off_a[1], b=b, Hb=Hb, Wb=Wb,
+           Cb=Cb, Csb=Csb, upb=up_b, ohb=off_b[0], owb=off_b[1], y=y, B=B, H=H, W=W, Cd=Cd)
+        ctx.cfg = (a.shape, None if b is None else b.shape, Ca, Cb, up_a, up_b, H, W, off_a, off_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ashape, bshape, Ca, Cb, up_a, up_b, H, W, off_a, off_b = ctx.cfg
+        dy = _req(dy, "dy")
+        B, _, _, Cd = dy.shape
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _empty(ashape, dy)
+            _k("vmtl_concat2_bwd", dy=dy, dx=da, B=B, H=H, W=W, Cd=Cd, c_off=0, Hs=ashape[1], Ws=ashape[2], C=Ca,
+               Cs=ashape[3], up=up_a, oh=off_a[0], ow=off_a[1])
+        if bshape is not None and ctx.needs_input_grad[1]:
+            db = _empty(bshape, dy)
+            _k("vmtl_concat2_bwd", dy=dy, dx=db, B=B, H=H, W=W, Cd=Cd, c_off=Ca, Hs=bshape[1], Ws=bshape[2], C=Cb,
+               Cs=bshape[3], up=up_b, oh=off_b[0], ow=off_b[1])
+        return da, db, None, None, None, None, None, None, None, None
+
+
+def concat2(a, Ca, b=None, Cb=0, up_a=1, up_b=1, out_hw=None, off_a=(0, 0), off_b=(0, 0)):
+    """Channel concat [a | b] into an (H, W) canvas; each source may be nearest-x2 upsampled
+    and/or placed at an offset (zeros elsewhere).  b=None: pure upsample / pad of a."""
+    if out_hw is None:
+        out_hw = (a.shape[1] * up_a, a.shape[2] * up_a)
+    return _Concat2.apply(a, b, Ca, Cb, up_a, up_b, out_hw[0], out_hw[1], tuple(off_a), tuple(off_b))
+
+
+# ----------------------------------------------------------------------------- pooling / bilinear
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        B, H, W, Cs = x.shape
+        y = _empty((B, H // 2, W // 2, Cs), x)
+        _k("vmtl_maxpool2_fwd", x=x, y=y, B=B, H=H, W=W, Cs=Cs)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        dx = _empty(x.shape, x)
+        _k("vmtl_maxpool2_bwd", x=x, dy=dy, dx=dx, B=B, H=H, W=W, Cs=Cs)
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _BilinearUp2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        B, H, W, Cs = x.shape
+        y = _empty((B, 2 * H, 2 * W, Cs), x)
+        _k("vmtl_bilinear_up2_fwd", x=x, y=y, B=B, H=H, W=W, Cs=Cs)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "dy")
+        B, H, W, Cs = ctx.shape
+        dx = _empty(ctx.shape, dy)
+        _k("vmtl_bilinear_up2_bwd", dy=dy, dx=dx, B=B, H=H, W=W, Cs=Cs)
+        return dx
+
+
+def bilinear_up2(x):
+    return _BilinearUp2.apply(x)
+
+
+# ----------------------------------------------------------------------------- squeeze-excite pieces
+class _SpatialMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        B, H, W, Cs = x.shape
+        y = _empty((B, 1, 1, Cs), x)
+        _k("vmtl_spatial_mean", x=x, y=y, B=B, HW=H * W, Cs=Cs)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "dy")
+        B, H, W, Cs = ctx.shape
+        dx = _empty(ctx.shape, dy)
+        _k("vmtl_channel_bcast", x=None, s=dy, y=dx, B=B, HW=H * W, Cs=Cs, mode=1)
+        return dx
+
+
+def spatial_mean(x):
+    return _SpatialMean.apply(x)
+
+
+class _ChannelScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _req(x, "x"), _req(s, "s")
+        B, H, W, Cs = x.shape
+        y = _empty(x.shape, x)
+        _k("vmtl_channel_bcast", x=x, s=s, y=y, B=B, HW=H * W, Cs=Cs, mode=0)
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        dx = ds = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x.shape, x)
+            _k("vmtl_channel_bcast", x=dy, s=s, y=dx, B=B, HW=H * W, Cs=Cs, mode=0)
+        if ctx.needs_input_grad[1]:
+            ds = _empty(s.shape, x)
+            _k("vmtl_channel_scale_bwd_s", x=x, dy=dy, ds=ds, B=B, HW=H * W, Cs=Cs)
+        return dx, ds
+
+
+def channel_scale(x, s):
+    return _ChannelScale.apply(x, s)
+
+
+# ----------------------------------------------------------------------------- cross-stitch (diagonal scale)
+class _Stitch(torch.autograd.Function):
+    """y = w[a, a, (c)] * x for task a; `weights` is the full (T,T[,C]) parameter
+    (reference models/cross_stitch_model.py:21-37).  Off-diagonal entries get zero gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weights, task, C):
+        x = _req(x, "x")
+        weights = _req(weights, "weights")
+        B, H, W, Cs = x.shape
+        T = weights.shape[0]
+        channel_wise = weights.dim() == 3
+        # element offset of w[task, task, 0] and the stride between channels
+        off = (task * T + task) * (weights.shape[2] if channel_wise else 1)
+        wview = weights.view(-1)[off:]
+        y = _empty(x.shape, x)
+        _k("vmtl_stitch", x=x, w=wview, y=y, M=B * H * W, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
+        ctx.save_for_backward(x, weights)
+        ctx.cfg = (task, C, channel_wise, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weights = ctx.saved_tensors
+        task, C, channel_wise, off = ctx.cfg
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x.shape, x)
+            _k("vmtl_stitch", x=dy, w=weights.view(-1)[off:], y=dx, M=M, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weights)
+            g = _colsum(x, dy, M, C, Cs, mode=1, reduce_all=0 if channel_wise else 1)
+            dw.view(-1)[off:off + g.numel()].copy_(g)
+        return dx, dw, None, None
+
+
+def stitch(x, weights, task, C):
+    return _Stitch.apply(x, weights, task, C)
+
+
+# ----------------------------------------------------------------------------- boundary layout + postprocess
+class _ToNHWC(torch.autograd.Function):
+    """(B,C,H,W) contiguous -> internal [B,H,W,Cs]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        B, C, H, W = x.shape
+        Cs = ceil4(C)
+        y = _empty((B, H, W, Cs), x)
+        _k("vmtl_nchw_to_nhwc", x=x, y=y, B=B, C=C, HW=H * W, Cs=Cs)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "dy")
+        B, H, W, Cs = dy.shape
+        dx = _empty((B, ctx.C, H, W), dy)
+        _k("vmtl_nhwc_to_nchw", x=dy, y=dx, B=B, C=ctx.C, HW=H * W, Cs=Cs)
+        return dx
+
+
+def to_nhwc(x):
+    return _ToNHWC.apply(x)
+
+
+class _ToNCHW(torch.autograd.Function):
+    """internal [B,H,W,Cs] -> (B,C,H,W) contiguous, the reference's output layout."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        x = _req(x, "x")
+        B, H, W, Cs = x.shape
+        y = _empty((B, C, H, W), x)
+        _k("vmtl_nhwc_to_nchw", x=x, y=y, B=B, C=C, HW=H * W, Cs=Cs)
+        ctx.Cs = Cs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _req(dy, "dy")
+        B, C, H, W = dy.shape
+        dx = _empty((B, H, W, ctx.Cs), dy)
+        _k("vmtl_nchw_to_nhwc", x=dy, y=dx, B=B, C=C, HW=H * W, Cs=ctx.Cs)
+        return dx, None
+
+
+def to_nchw(x, C):
+    return _ToNCHW.apply(x, C)
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "x")
+        y = _empty(x.shape, x)
+        _k("vmtl_eltwise", a=x, b=None, y=y, mode=1, total=x.numel())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _req(dy, "dy")
+        dx = _empty(y.shape, y)
+        _k("vmtl_eltwise", a=y, b=dy, y=dx, mode=2, total=y.numel())
+        return dx
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)
+
+
+def argmax_channels(logits):
+    """argmax over dim 1 of (B,C,H,W) logits -> int64 (B,H,W); reads NCHW or channels-last strides in place."""
+    if not logits.is_cuda:
+        raise RuntimeError("argmax_channels: tensor is not on the GPU (no CPU fallback on the hot path)")
+    B, C, H, W = logits.shape
+    z = logits.detach()
+    if not (z.stride(3) * W == z.stride(2) and z.dtype == torch.float32):
+        z = z.float().contiguous()
+    out = torch.empty((B, H, W), dtype=torch.int64, device=z.device)
+    _k("vmtl_argmax_channels", z=z, out=out, B=B, HW=H * W, C=C, sb=z.stride(0), sc=z.stride(1), sp=z.stride(3))
+    return out
+
+
+# ----------------------------------------------------------------------------- losses
+class _CrossEntropy(torch.autograd.Function):
+    """mean_{b,h,w} -log_softmax(logits)[target]; logits (B,C,H,W) NCHW-contiguous."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = _req(logits, "logits")
+        if target.dtype != torch.int64:
+            raise TypeError("cross_entropy: target must be int64 class indices")
+        target = target.contiguous()
+        B, C, H, W = logits.shape
+        if tuple(target.shape) != (B, H, W):
+            raise ValueError(f"cross_entropy: target shape {tuple(target.shape)} does not match logits {(B, H, W)}")
+        P = B * H * W
+        lse = _empty((P,), logits)
+        loss = _empty((), logits)
+        ws = torch.empty((lib().raw("vmtl_ce_workspace_bytes")(P) // 8,), dtype=torch.float64, device=logits.device)
+        _k("vmtl_ce_fwd", logits=logits, target=target, lse=lse, loss=loss, workspace=ws, B=B, HW=H * W, C=C,
+           sb=C * H * W, sc=H * W, sp=1)
+        ctx.save_for_backward(logits, target, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        g = _req(g, "grad_output")
+        dl = _empty(logits.shape, logits)
+        _k("vmtl_ce_bwd", logits=logits, target=target, lse=lse, grad_out=g, dlogits=dl, B=B, HW=H * W, C=C,
+           sb=C * H * W, sc=H * W, sp=1)
+        return dl, None
+
+
+def cross_entropy(logits, target):
+    return _CrossEntropy.apply(logits, target)
+
+
+class _SILog(torch.autograd.Function):
+    """reference losses.py:29-36 on predictions in (0,1); pred and target hold the same number of elements."""
+
+    @staticmethod
+    def forward(ctx, pred, target, min_depth):
+        pred, target = _req(pred, "pred"), _req(target, "target")
+        if pred.numel() != target.numel():
+            raise ValueError("silog: pred and target must have the same number of elements")
+        P = pred.numel()
+        loss, stats = _empty((), pred), _empty((3,), pred)
+        ws = torch.empty((lib().raw("vmtl_silog_workspace_bytes")(P) // 8,), dtype=torch.float64, device=pred.device)
+        _k("vmtl_silog_fwd", pred=pred, target=target, min_depth=min_depth, loss=loss, stats=stats, workspace=ws, P=P)
+        ctx.save_for_backward(pred, target, stats)
+        ctx.min_depth = min_depth
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        g = _req(g, "grad_output")
+        dp = _empty(pred.shape, pred)
+        _k("vmtl_silog_bwd", pred=pred, target=target, stats=stats, grad_out=g, min_depth=ctx.min_depth, dpred=dp,
+           P=pred.numel())
+        return dp, None, None
+
+
+def silog(pred, target, min_depth=1e-3):
+    return _SILog.apply(pred, target, float(min_depth))
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = _req(pred, "pred"), _req(target, "target")
+        if pred.numel() != target.numel():
+            raise ValueError("l1: pred and target must have the same number of elements")
+        P = pred.numel()
+        loss = _empty((), pred)
+        ws = torch.empty((lib().raw("vmtl_silog_workspace_bytes")(P) // 8,), dtype=torch.float64, device=pred.device)
+        _k("vmtl_l1_fwd", pred=pred, target=target, loss=loss, workspace=ws, P=P)
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        g = _req(g, "grad_output")
+        dp = _empty(pred.shape, pred)
+        _k("vmtl_l1_bwd", pred=pred, target=target, grad_out=g, dpred=dp, P=pred.numel())
+        return dp, None
+
+
+def l1_loss(pred, target):
+    return _L1.apply(pred, target)
+
+
+# ----------------------------------------------------------------------------- optimizer
+def adam_step(p, g, m, v, step_t, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """Fused torch.optim.Adam update over flat fp32 buffers; step_t is a 1-element device
+    tensor holding the (already incremented) step count."""
+    _k("vmtl_adam_step", p=p, g=g, m=m, v=v, step_ptr=step_t, lr=lr, b1=betas[0], b2=betas[1], eps=eps,
+       weight_decay=weight_decay, grad_scale=grad_scale, n=p.numel())
