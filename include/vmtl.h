@@ -127,6 +127,11 @@ int vmtl_l1_fwd(const float* pred, const float* target, float* loss, void* works
 int vmtl_l1_bwd(const float* pred, const float* target, const float* grad_out, float* dpred, long long P,
                 void* stream);
 
+/* ---- per-step metrics (lit_module.py:48-69,106-118: torchmetrics Accuracy / Jaccard / FBeta) ---- */
+int vmtl_confusion_matrix(const long long* pred, const long long* target, int* cm, long long P, int C,
+                          void* stream);
+int vmtl_segm_metrics(const int* cm, int C, float beta, float* out, void* stream);
+
 /* ---- optimizer (training_lit.py:51,87: torch.optim.Adam) ---------------------------------- */
 int vmtl_adam_step(float* p, const float* g, float* m, float* v, const float* step_ptr, float lr, float b1,
                    float b2, float eps, float weight_decay, float grad_scale, long long n, void* stream);

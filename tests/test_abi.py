@@ -1,0 +1,46 @@
+"""-m "not gpu": the C-ABI library builds/loads on a GPU-less box and exports every symbol that
+include/vmtl.h declares; the product path refuses CPU tensors instead of falling back."""
+import ctypes
+
+import pytest
+import torch
+
+
+def test_header_symbols_exported():
+    from vision_mtl_amd._lib import HEADER, LIB_PATH, lib, parse_header
+
+    protos = parse_header(HEADER)
+    assert len(protos) >= 40
+    dll = ctypes.CDLL(str(LIB_PATH)) if LIB_PATH.exists() else lib()._dll
+    for name in protos:
+        assert hasattr(dll, name), f"{name} declared in vmtl.h but not exported"
+    assert lib().raw("vmtl_version")().startswith(b"vmtl")
+
+
+def test_host_only_entry_points():
+    from vision_mtl_amd._lib import lib
+
+    l = lib()
+    assert l.raw("vmtl_reduce_rows")(1) == 1
+    assert l.raw("vmtl_reduce_rows")(10 ** 6) == 1024
+    assert l.raw("vmtl_conv2d_stats_rows")(32, 128, 256, 36) == 32 * 128 * 256 // 128
+    assert l.raw("vmtl_ce_workspace_bytes")(1 << 20) % 8 == 0
+    assert l.raw("vmtl_silog_workspace_bytes")(1 << 20) % 8 == 0
+
+
+def test_no_cpu_fallback():
+    from vision_mtl_amd import ops
+
+    x = torch.zeros(1, 4, 4, 4)
+    w = torch.zeros(4, 4, 3, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv2d(x, w, None, 1, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cross_entropy(torch.zeros(1, 3, 2, 2), torch.zeros(1, 2, 2, dtype=torch.int64))
+
+
+def test_callk_rejects_wrong_names():
+    from vision_mtl_amd._lib import lib
+
+    with pytest.raises(TypeError):
+        lib().callk("vmtl_maxpool2_fwd", x=None, y=None, B=1, H=2, W=2, Cs=4)  # stream missing

@@ -1,0 +1,115 @@
+"""Execution helpers shared by the three model mirrors.
+
+The models keep their parameters in ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d`` /
+``nn.ConvTranspose2d`` modules — used purely as parameter containers, so ``state_dict()`` keys,
+shapes, default initialisation and optimizer behaviour are exactly the reference's — while
+the arithmetic goes through the HIP kernels in :mod:`vision_mtl_amd.ops`.  ``Act`` is the
+internal activation handle: an NHWC tensor with zero-padded channels plus its logical
+channel count.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+@dataclass
+class Act:
+    t: torch.Tensor  # [B, H, W, Cs] fp32, channels [C, Cs) are zero
+    C: int
+
+    @property
+    def hw(self):
+        return self.t.shape[1], self.t.shape[2]
+
+
+def from_nchw(x: torch.Tensor) -> Act:
+    if x.dim() != 4:
+        raise ValueError(f"expected a (B, C, H, W) tensor, got shape {tuple(x.shape)}")
+    return Act(ops.to_nhwc(x.float()), x.shape[1])
+
+
+def to_nchw(a: Act) -> torch.Tensor:
+    return ops.to_nchw(a.t, a.C)
+
+
+def _pair(v):
+    return v[0] if isinstance(v, (tuple, list)) else v
+
+
+def conv(x: Act, m: nn.Conv2d) -> Act:
+    """Dense conv (+bias), no normalisation."""
+    if m.groups != 1:
+        raise ValueError("conv(): use dwconv() for depthwise modules")
+    y = ops.conv2d(x.t, m.weight, m.bias, _pair(m.stride), _pair(m.padding))
+    return Act(y, m.out_channels)
+
+
+def conv_bn_act(x: Act, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | None = None,
+                res: Act | None = None) -> Act:
+    """act(BN(conv(x))) [* mul] [+ res] with the BatchNorm column sums taken from the conv epilogue."""
+    train = bn.training
+    if c.groups == 1:
+        out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train)
+        y, stats = out if train else (out, None)
+    else:
+        if c.groups != c.in_channels or c.in_channels != c.out_channels or c.bias is not None:
+            raise ValueError("only depthwise grouped convs are supported")
+        y, stats = ops.dwconv(x.t, c.weight, _pair(c.stride), _pair(c.padding)), None
+    return bn_act(Act(y, c.out_channels), bn, act, mul, res, stats)
+
+
+def bn_act(x: Act, bn: nn.BatchNorm2d, act: int, mul: Act | None = None, res: Act | None = None,
+           stats=None) -> Act:
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    y = ops.bn_act(x.t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, x.C,
+                   bn.training, momentum, bn.eps, act, mul=None if mul is None else mul.t,
+                   res=None if res is None else res.t, stats=stats)
+    return Act(y, x.C)
+
+
+def activation(x: Act, act: int) -> Act:
+    return Act(ops.activation(x.t, act, x.C), x.C)
+
+
+def dwconv(x: Act, m: nn.Conv2d) -> Act:
+    return Act(ops.dwconv(x.t, m.weight, _pair(m.stride), _pair(m.padding)), m.out_channels)
+
+
+def conv_transpose(x: Act, m: nn.ConvTranspose2d) -> Act:
+    return Act(ops.conv_transpose2x2(x.t, m.weight, m.bias), m.out_channels)
+
+
+def cat(a: Act, b: Act) -> Act:
+    """torch.cat((a, b), dim=1) for equal spatial sizes."""
+    if a.hw != b.hw:
+        raise AssertionError(f"cat: spatial sizes differ: {a.hw} vs {b.hw}")
+    return Act(ops.concat2(a.t, a.C, b.t, b.C), a.C + b.C)
+
+
+def pad_cat(x1: Act, x2: Act) -> Act:
+    """reference utils/model_utils.py:46-58: zero-pad x1 into x2's canvas, cat [x2, x1]."""
+    (h1, w1), (h2, w2) = x1.hw, x2.hw
+    dy, dx = h2 - h1, w2 - w1
+    if dy < 0 or dx < 0:
+        raise ValueError("pad_cat: x1 must not be larger than x2")
+    return Act(ops.concat2(x2.t, x2.C, x1.t, x1.C, out_hw=(h2, w2), off_b=(dy // 2, dx // 2)), x1.C + x2.C)
+
+
+def up2_cat(x: Act, skip: Act | None) -> Act:
+    """smp DecoderBlock entry: nearest x2 upsample of x, then cat [x, skip]."""
+    if skip is None:
+        return Act(ops.concat2(x.t, x.C, up_a=2), x.C)
+    return Act(ops.concat2(x.t, x.C, skip.t, skip.C, up_a=2), x.C + skip.C)
+
+
+def maxpool2(x: Act) -> Act:
+    return Act(ops.maxpool2(x.t), x.C)
+
+
+def bilinear_up2(x: Act) -> Act:
+    return Act(ops.bilinear_up2(x.t), x.C)
