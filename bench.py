@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the full multi-task training step graph
+(model forward -> CrossEntropy + SILog -> backward to every parameter [+ one RCCL gradient
+all-reduce when N > 1]) on synthetic data, fp32, model in train mode — BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Besides the driver contract it carries
+  roofline     : the implicit-GEMM conv kernel (conv_igemm_kernel, forward + data-gradient launches
+                 of one step) timed launch-by-launch with HIP events on the launch stream;
+                 achieved = algorithmic FLOPs per launch / average launch duration, peak = 157.3 TF
+                 (exact-fp32 MFMA, MI355X_MICROARCH.md)
+  cpu_baseline : the oracle (CPU restatement of the same step graph, oracle/) timed on the host
+                 cores of this box on a bounded sample; a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS_FP32_MFMA = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+# algorithmic GFLOP per image, fwd + bwd; used only to quote whole-step TFLOP/s
+STEP_GFLOP_PER_IMG = {("basic", 128, 256): 33.07, ("basic", 256, 256): 66.14, ("mtan", 256, 256): 201.2}
+
+
+def build(args, device):
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)  # reference cfg.py:194
+    ns = argparse.Namespace(model_name=args.model, backbone_weights=None, channel_wise_stitching=True)
+    model = build_model(ns, argparse.Namespace(num_classes=args.classes)).to(device).train()
+    module = MTLModule(model, num_classes=args.classes, device=str(device))
+    module.compute_metrics = False  # the metric is fwd + losses + bwd ("no metrics, no logging")
+    return model, module
+
+
+def make_batch(args, device, rank):
+    from oracle.losses import synthetic_batch
+
+    b = synthetic_batch(args.batch, args.height, args.width, args.classes, seed=11 + rank)
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def time_conv_kernels(module, batch, reps=3):
+    """Replay every implicit-GEMM launch of one training step on its own, bracketed by HIP events on
+    the launch stream.  Returns per-family (igemm = fwd+dgrad kernel, wgrad) totals."""
+    from vision_mtl_amd import ops
+    from vision_mtl_amd._lib import lib
+
+    ops._RECORD = []
+    try:
+        loss = module.training_step(batch, 0)
+        loss.backward()
+    finally:
+        rec, ops._RECORD = ops._RECORD, None
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    fam = {"vmtl_conv2d_fwd": dict(flop=0.0, ms=0.0, launches=0), "vmtl_conv2d_wgrad": dict(flop=0.0, ms=0.0, launches=0)}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, kw, flop in rec:  # flop = algorithmic FLOPs of the launch (logical channels, no padding lanes)
+        lib().callk(name, stream=stream, **kw)  # warm
+        e0.record()
+        for _ in range(reps):
+            lib().callk(name, stream=stream, **kw)
+        e1.record()
+        e1.synchronize()
+        f = fam[name]
+        f["flop"] += flop
+        f["ms"] += e0.elapsed_time(e1) / reps
+        f["launches"] += 1
+    return fam
+
+
+def cpu_baseline(args):
+    """Oracle step (fwd + CE + SILog + bwd, train mode) on the host cores; bounded sample."""
+    from oracle.losses import step_losses, synthetic_batch
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    bs = 8  # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    ns = argparse.Namespace(model_name=args.model, backbone_weights=None, channel_wise_stitching=True)
+    sd = build_model(ns, argparse.Namespace(num_classes=args.classes)).state_dict()
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    batch = synthetic_batch(bs, args.height, args.width, args.classes, seed=11)
+    if args.model == "basic":
+        from oracle.unet_mobilenetv3 import basic_forward as fwd
+
+        run = lambda: fwd(sd, batch["img"], True)
+    elif args.model == "mtan":
+        from oracle.mtan import mtan_forward
+
+        run = lambda: mtan_forward(sd, batch["img"], ["depth", "segm"], 4, True)
+    else:
+        from oracle.cross_stitch import csnet_forward
+
+        run = lambda: csnet_forward(sd, batch["img"], ["depth", "segm"], True)
+
+    def step():
+        for v in sd.values():
+            if v.requires_grad:
+                v.grad = None
+        step_losses(run(), batch["mask"], batch["depth"])["loss"].backward()
+
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle {args.model} {args.height}x{args.width} bs={bs} fwd+CE+SILog+bwd, {n} steps in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="basic", choices=["basic", "mtan", "csnet"])
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=19)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--adam", action="store_true", help="include the fused Adam update in the timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from vision_mtl_amd import dp
+
+    rank, world, local_rank = dp.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    model, module = build(args, device)
+    arena = dp.FlatArena(model)
+    batch = make_batch(args, device, rank)
+    import torch.distributed as dist
+
+    def step():
+        loss = module.training_step(batch, 0)
+        loss.backward()
+        return loss
+
+    def after_step():
+        scale = arena.all_reduce_mean()  # one RCCL all-reduce of the flat gradient (no-op at N=1)
+        if args.adam:
+            arena.adam_step(lr=5e-4, grad_scale=scale)
+
+    # eager warm-up (also primes allocator pools and kernel code objects)
+    for _ in range(2):
+        step()
+        after_step()
+        module.step_outputs["train"]["loss"].clear()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        for k in module.step_outputs["train"]:
+            module.step_outputs["train"][k].clear()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+        after_step()
+
+    for _ in range(args.warmup):
+        run_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float((static_loss if graph is not None else step()).item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        out = {
+            "metric": f"images/sec fwd+bwd, {args.model} model {args.height}x{args.width}",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.height}x{args.width} C={args.classes} bs={args.batch}/GPU, "
+                                   f"train-mode fwd + CE + SILog + bwd" + (" + Adam" if args.adam else "")
+                                   + (" + 1 RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "launch": "eager" if graph is None else "hipGraph replay", "loss": round(loss_val, 5)},
+        }
+        gf = STEP_GFLOP_PER_IMG.get((args.model, args.height, args.width))
+        if gf:
+            tf = gf * value / world / 1e3
+            out["config"]["step_tflops_per_gpu"] = round(tf, 2)
+            out["config"]["step_frac_of_fp32_mfma_peak"] = round(tf / PEAK_TFLOPS_FP32_MFMA, 4)
+        if not args.no_roofline:
+            fam = time_conv_kernels(module, batch)
+            ig = fam["vmtl_conv2d_fwd"]
+            ach = ig["flop"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": None,
+                               "kernel": "conv_igemm_kernel (forward + data-gradient launches of one step)",
+                               "launches_per_step": ig["launches"],
+                               "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
+                               "flop_per_launch": round(ig["flop"] / max(ig["launches"], 1)),
+                               "ms_per_step_in_kernel": round(ig["ms"], 3)}
+            wg = fam["vmtl_conv2d_wgrad"]
+            if wg["ms"] > 0:
+                wach = wg["flop"] / (wg["ms"] * 1e-3) / 1e12
+                out["roofline"]["wgrad_kernel"] = {"achieved": round(wach, 2), "frac": round(wach / PEAK_TFLOPS_FP32_MFMA, 4),
+                                                   "launches_per_step": wg["launches"],
+                                                   "ms_per_step_in_kernel": round(wg["ms"], 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""-m gpu: the HIP `basic` model (MobileNetV3-Large encoder + U-Net decoder 540..33 + two 3x3 heads)
+against the CPU oracle (oracle/unet_mobilenetv3.py) on identical weights and inputs: outputs and
+step loss within 1e-4, every parameter gradient within 1e-3 of its max magnitude.
+(`basic` is reference-unpinned: smp/timm are not available offline, see the oracle header.)"""
+import argparse
+
+import pytest
+import torch
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu_step(sd, batch, training=True):
+    from oracle.losses import step_losses
+    from oracle.unet_mobilenetv3 import basic_forward
+
+    sd = {k: v.clone() for k, v in sd.items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    out = basic_forward(sd, batch["img"], training)
+    losses = step_losses(out, batch["mask"], batch["depth"])
+    losses["loss"].backward()
+    return out, losses, leaves, sd
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 32, 64)])
+def test_basic_step_matches_oracle(dev, shape):
+    from oracle.losses import synthetic_batch
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    args = argparse.Namespace(model_name="basic", backbone_weights=None)
+    model = build_model(args, argparse.Namespace(num_classes=19))
+    # perturb BN affine params / running stats so they are not the trivial 1/0
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and ("bn" in n or ".1." in n):
+                p.copy_(p + torch.randn(p.shape, generator=g) * 0.1)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    B, H, W = shape
+    batch = synthetic_batch(B, H, W, 19, seed=11, masked=0.1)
+    out_ref, losses_ref, leaves, sd_after = _cpu_step(sd0, batch, training=True)
+
+    model = model.to(dev).train()
+    module = MTLModule(model, num_classes=19, device=str(dev))
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    out = model(dbatch["img"])
+    for t in ("depth", "segm"):
+        assert out[t].shape == out_ref[t].shape and out[t].is_contiguous()
+        assert_close(out[t].detach().cpu(), out_ref[t].detach(), tol=1e-4, what=f"train out {t}")
+    model.load_state_dict(sd0)  # undo the BN buffer update of the probe forward
+    loss = module.training_step(dbatch, 0)
+    loss.backward()
+    assert_close(loss.detach().cpu(), losses_ref["loss"].detach(), tol=1e-4, what="step loss")
+    gscale = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        assert p.grad is not None, f"no grad for {k}"
+        assert_close(p.grad.cpu(), leaves[k].grad, tol=1e-3, atol=1e-6 * gscale, what=f"grad {k}")
+    sd = model.state_dict()
+    for k, v in sd_after.items():
+        if "running" in k:
+            assert_close(sd[k].cpu(), v.detach(), tol=1e-4, what=k)
+    # eval mode
+    from oracle.unet_mobilenetv3 import basic_forward
+
+    with torch.no_grad():
+        ref_eval = basic_forward({k: v.detach().clone() for k, v in sd_after.items()}, batch["img"], False)
+        model.eval()
+        oe = model.predict(dbatch["img"])
+    for t in ("depth", "segm"):
+        assert_close(oe[t].cpu(), ref_eval[t], tol=1e-4, what=f"eval out {t}")
+
+
+def test_build_model_errors(dev):
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    with pytest.raises(NotImplementedError):
+        build_model(argparse.Namespace(model_name="nope", backbone_weights=None), argparse.Namespace(num_classes=3))
+    with pytest.raises(RuntimeError, match="download"):
+        build_model(argparse.Namespace(model_name="basic", backbone_weights="imagenet"),
+                    argparse.Namespace(num_classes=3))

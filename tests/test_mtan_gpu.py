@@ -35,9 +35,11 @@ def test_mtan_matches_reference_golden(dev, name):
     loss.backward()
     assert_close(loss.detach().cpu(), fx["loss"], tol=1e-4, what="step loss")
     grads = dict(model.named_parameters())
+    gscale = max(float(g.abs().max()) for g in fx["grads"].values())
     for k, g in fx["grads"].items():
         assert grads[k].grad is not None, f"no gradient for {k}"
-        assert_close(grads[k].grad.cpu(), g, tol=1e-3, what=f"grad {k}")
+        # atol: biases in front of a train-mode BatchNorm have an analytically zero gradient
+        assert_close(grads[k].grad.cpu(), g, tol=1e-3, atol=1e-6 * gscale, what=f"grad {k}")
     # BN running statistics and counters were updated like the reference's
     sd = model.state_dict()
     for k, v in fx["state_dict_after"].items():

@@ -30,8 +30,9 @@ def test_mtan_oracle_matches_reference(name):
     for t in tasks:
         assert_close(out[t].detach(), fx["out_train"][t], tol=1e-5, what=f"train out {t}")
     assert_close(losses["loss"].detach(), fx["loss"], tol=1e-5, what="loss")
+    gscale = max(float(g.abs().max()) for g in fx["grads"].values())
     for k, g in fx["grads"].items():
-        assert_close(leaves[k].grad, g, tol=2e-4, what=f"grad {k}")
+        assert_close(leaves[k].grad, g, tol=2e-4, atol=1e-6 * gscale, what=f"grad {k}")
     for k, v in fx["state_dict_after"].items():
         if "running" in k:
             assert_close(sd[k].detach(), v, tol=1e-5, what=k)

@@ -23,6 +23,9 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def assert_close(a, b, tol=1e-4, what=""):
-    e = rel_err(a, b)
-    assert e <= tol, f"{what}: max-abs error / max-abs reference = {e:.3e} > {tol}"
+def assert_close(a, b, tol=1e-4, what="", atol=0.0):
+    """max|a-b| <= tol * max|b| + atol.  atol is for quantities that are analytically zero (e.g. the
+    gradient of a conv bias that feeds a train-mode BatchNorm), where both sides are rounding noise."""
+    a, b = a.double(), b.double()
+    err, ref = (a - b).abs().max().item(), b.abs().max().item()
+    assert err <= tol * ref + atol, f"{what}: max-abs error {err:.3e} vs reference magnitude {ref:.3e} (tol {tol}, atol {atol})"

@@ -183,13 +183,12 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int Cs, float* sum_dz,
                                        float* sum_dzx) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cs) return;
+  if (c >= C) return;  // exactly C entries are written: the outputs may be slots of a flat gradient arena
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int b = 0; b < nblk; ++b) {
-      s1 += (double)partial[((size_t)b * 2 + 0) * Cs + c];
-      s2 += (double)partial[((size_t)b * 2 + 1) * Cs + c];
-    }
+  for (int b = 0; b < nblk; ++b) {
+    s1 += (double)partial[((size_t)b * 2 + 0) * Cs + c];
+    s2 += (double)partial[((size_t)b * 2 + 1) * Cs + c];
+  }
   sum_dz[c] = (float)s1;
   sum_dzx[c] = (float)s2;
 }
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 // One call = reduce + finalize + apply.  `partial` needs vmtl_reduce_rows(M)*2*Cs floats.
-// sum_dz / sum_dzx ([Cs]) are the bias / weight gradients of the BatchNorm.
+// sum_dz / sum_dzx ([C]) are the bias / weight gradients of the BatchNorm.
 extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, const float* mul, float* dmul, float* partial,
                            float* sum_dz, float* sum_dzx, float* dx, int M, int C, int Cs, int act, int training,

@@ -1,0 +1,38 @@
+"""Host-side mirror of reference vision_mtl/models/basic_model.py (hard parameter sharing:
+one backbone, two 3x3 heads) on the HIP kernels."""
+from __future__ import annotations
+
+import typing as t
+
+import torch
+from torch import nn
+
+from .. import layers as L
+from .unet_mobilenetv3 import Backbone, SegmentationHead
+
+
+class BasicMTLModel(nn.Module):
+    """reference models/basic_model.py:10-60.  forward(x: (B,3,H,W)) -> {"depth": (B,1,H,W), "segm": (B,C,H,W)}."""
+
+    def __init__(self, segm_classes: int, activation: t.Any = None, encoder_name: str = "timm-mobilenetv3_large_100",
+                 encoder_weights: t.Optional[str] = "imagenet", decoder_first_channel: int = 256,
+                 num_decoder_layers: int = 5, in_channels: int = 3):
+        super().__init__()
+        self.backbone = Backbone(encoder_name=encoder_name, encoder_weights=encoder_weights,
+                                 decoder_first_channel=decoder_first_channel, num_decoder_layers=num_decoder_layers,
+                                 in_channels=in_channels)
+        last = self.backbone.decoder_channels[-1]
+        self.segm_head = SegmentationHead(last, segm_classes, activation=activation, kernel_size=3)
+        self.depth_head = SegmentationHead(last, 1, activation=activation, kernel_size=3)
+
+    def forward(self, x: torch.Tensor) -> t.Dict[str, torch.Tensor]:
+        dec = self.backbone.run(L.from_nchw(x))
+        depth = L.to_nchw(self.depth_head.run(dec))
+        segm = L.to_nchw(self.segm_head.run(dec))
+        return dict(depth=depth, segm=segm)
+
+    @torch.no_grad()
+    def predict(self, x: torch.Tensor) -> t.Dict[str, torch.Tensor]:
+        if self.training:
+            self.eval()
+        return self.forward(x)

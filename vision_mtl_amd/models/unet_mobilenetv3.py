@@ -1,0 +1,294 @@
+"""MobileNetV3-Large feature encoder + U-Net decoder + segmentation head on the HIP kernels.
+
+The reference gets these from third-party packages that are not under /root/reference and not
+installable offline:  segmentation_models_pytorch==0.3.3 (requirements.txt:14) -> timm==0.9.2,
+instantiated at reference vision_mtl/utils/model_utils.py:25-34 (smp.Unet(encoder_name=
+"timm-mobilenetv3_large_100", encoder_depth=5, decoder_channels=...)) and
+models/basic_model.py:30-41 / utils/model_utils.py:125-130 (SegmentationHead(kernel_size=3)).
+This file restates their published architecture with the same module
+names, so state_dict keys / shapes match what smp+timm produce; results at this boundary are
+"reference-unpinned" (no reference test or importable code pins them) and are checked against
+the CPU oracle in oracle/unet_mobilenetv3.py instead.
+
+Param-less children (act / drop / Identity modules) are kept on purpose: the reference's CSNet
+(models/cross_stitch_model.py:102-157) walks named_modules() of exactly this tree.
+"""
+from __future__ import annotations
+
+import math
+import typing as t
+
+import torch
+from torch import nn
+
+from .. import layers as L
+from ..ops import ACT_HSIGMOID, ACT_HSWISH, ACT_NONE, ACT_RELU
+
+_ACT_CODE = {"relu": ACT_RELU, "hard_swish": ACT_HSWISH, None: ACT_NONE}
+
+
+def _act_module(name):
+    return {"relu": nn.ReLU, "hard_swish": nn.Hardswish, None: nn.Identity}[name]()
+
+
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+# timm `mobilenetv3_large_100` arch_def: (type, kernel, stride, expansion, out_channels, se, act)
+ARCH = [
+    [("ds", 3, 1, 1.0, 16, False, "relu")],
+    [("ir", 3, 2, 4.0, 24, False, "relu"), ("ir", 3, 1, 3.0, 24, False, "relu")],
+    [("ir", 5, 2, 3.0, 40, True, "relu"), ("ir", 5, 1, 3.0, 40, True, "relu"), ("ir", 5, 1, 3.0, 40, True, "relu")],
+    [("ir", 3, 2, 6.0, 80, False, "hard_swish"), ("ir", 3, 1, 2.5, 80, False, "hard_swish"),
+     ("ir", 3, 1, 2.3, 80, False, "hard_swish"), ("ir", 3, 1, 2.3, 80, False, "hard_swish")],
+    [("ir", 3, 1, 6.0, 112, True, "hard_swish"), ("ir", 3, 1, 6.0, 112, True, "hard_swish")],
+    [("ir", 5, 2, 6.0, 160, True, "hard_swish"), ("ir", 5, 1, 6.0, 160, True, "hard_swish"),
+     ("ir", 5, 1, 6.0, 160, True, "hard_swish")],
+    [("cn", 1, 1, 1.0, 960, False, "hard_swish")],
+]
+STEM = 16
+
+
+class BatchNormAct2d(nn.BatchNorm2d):
+    """timm BatchNormAct2d: BatchNorm2d parameters + child modules `drop` (Identity) and `act`."""
+
+    def __init__(self, num_features, act=None):
+        super().__init__(num_features)
+        self.drop = nn.Identity()
+        self.act = _act_module(act)
+        self.act_code = _ACT_CODE[act]
+
+
+class SqueezeExcite(nn.Module):
+    """timm SqueezeExcite(gate=hard_sigmoid, act=ReLU): x * hsigmoid(W_e relu(W_r mean_hw(x) + b_r) + b_e)."""
+
+    def __init__(self, chs, rd_chs):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(chs, rd_chs, 1, bias=True)
+        self.act1 = nn.ReLU(inplace=True)
+        self.conv_expand = nn.Conv2d(rd_chs, chs, 1, bias=True)
+        self.gate = nn.Hardsigmoid()
+
+    def run(self, x: L.Act) -> L.Act:
+        s = L.Act(L.ops.spatial_mean(x.t), x.C)
+        s = L.activation(L.conv(s, self.conv_reduce), ACT_RELU)
+        s = L.activation(L.conv(s, self.conv_expand), ACT_HSIGMOID)
+        return L.Act(L.ops.channel_scale(x.t, s.t), x.C)
+
+
+class DepthwiseSeparableConv(nn.Module):
+    def __init__(self, in_chs, out_chs, k, stride, act):
+        super().__init__()
+        self.has_skip = stride == 1 and in_chs == out_chs
+        self.conv_dw = nn.Conv2d(in_chs, in_chs, k, stride, (k - 1) // 2, groups=in_chs, bias=False)
+        self.bn1 = BatchNormAct2d(in_chs, act)
+        self.se = nn.Identity()
+        self.conv_pw = nn.Conv2d(in_chs, out_chs, 1, bias=False)
+        self.bn2 = BatchNormAct2d(out_chs, None)
+        self.drop_path = nn.Identity()
+
+    def run(self, x: L.Act) -> L.Act:
+        y = L.conv_bn_act(x, self.conv_dw, self.bn1, self.bn1.act_code)
+        return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=x if self.has_skip else None)
+
+
+class InvertedResidual(nn.Module):
+    def __init__(self, in_chs, out_chs, k, stride, exp, se, act):
+        super().__init__()
+        mid = make_divisible(in_chs * exp)
+        self.has_skip = stride == 1 and in_chs == out_chs
+        self.conv_pw = nn.Conv2d(in_chs, mid, 1, bias=False)
+        self.bn1 = BatchNormAct2d(mid, act)
+        self.conv_dw = nn.Conv2d(mid, mid, k, stride, (k - 1) // 2, groups=mid, bias=False)
+        self.bn2 = BatchNormAct2d(mid, act)
+        self.se = SqueezeExcite(mid, make_divisible(mid * 0.25)) if se else nn.Identity()
+        self.conv_pwl = nn.Conv2d(mid, out_chs, 1, bias=False)
+        self.bn3 = BatchNormAct2d(out_chs, None)
+        self.drop_path = nn.Identity()
+
+    def run(self, x: L.Act) -> L.Act:
+        y = L.conv_bn_act(x, self.conv_pw, self.bn1, self.bn1.act_code)
+        y = L.conv_bn_act(y, self.conv_dw, self.bn2, self.bn2.act_code)
+        if isinstance(self.se, SqueezeExcite):
+            y = self.se.run(y)
+        return L.conv_bn_act(y, self.conv_pwl, self.bn3, ACT_NONE, res=x if self.has_skip else None)
+
+
+class ConvBnAct(nn.Module):
+    def __init__(self, in_chs, out_chs, k, act):
+        super().__init__()
+        self.conv = nn.Conv2d(in_chs, out_chs, k, 1, (k - 1) // 2, bias=False)
+        self.bn1 = BatchNormAct2d(out_chs, act)
+        self.drop_path = nn.Identity()
+
+    def run(self, x: L.Act) -> L.Act:
+        return L.conv_bn_act(x, self.conv, self.bn1, self.bn1.act_code)
+
+
+class MobileNetV3Features(nn.Module):
+    """timm.create_model("mobilenetv3_large_100", features_only=True): conv_stem, bn1, act1, blocks."""
+
+    def __init__(self, in_chans=3):
+        super().__init__()
+        self.conv_stem = nn.Conv2d(in_chans, STEM, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(STEM)
+        self.act1 = nn.Hardswish()
+        stages, c = [], STEM
+        for stage in ARCH:
+            blocks = []
+            for kind, k, s, e, out, se, act in stage:
+                if kind == "ds":
+                    blocks.append(DepthwiseSeparableConv(c, out, k, s, act))
+                elif kind == "ir":
+                    blocks.append(InvertedResidual(c, out, k, s, e, se, act))
+                else:
+                    blocks.append(ConvBnAct(c, out, k, act))
+                c = out
+            stages.append(nn.Sequential(*blocks))
+        self.blocks = nn.Sequential(*stages)
+        self._init_weights()
+
+    def _init_weights(self):  # timm efficientnet_init_weights
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+                nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_out))
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+
+class MobileNetV3Encoder(nn.Module):
+    """smp encoders/timm_mobilenetv3.py: stages = [Identity, stem+blocks[0], blocks[1], blocks[2],
+    blocks[3:5], blocks[5:]] -> features with 3,16,24,40,112,960 channels at strides 1..32."""
+
+    out_channels = (3, 16, 24, 40, 112, 960)
+
+    def __init__(self, in_channels=3, depth=5):
+        super().__init__()
+        self._depth = depth
+        self.model = MobileNetV3Features(in_channels)
+
+    def run(self, x: L.Act) -> t.List[L.Act]:
+        m = self.model
+        feats = [x]
+        y = L.conv_bn_act(x, m.conv_stem, m.bn1, ACT_HSWISH)
+        groups = [[0], [1], [2], [3, 4], [5, 6]]
+        for g in groups[: self._depth]:
+            for si in g:
+                for blk in m.blocks[si]:
+                    y = blk.run(y)
+            feats.append(y)
+        return feats
+
+
+class Conv2dReLU(nn.Sequential):
+    def __init__(self, in_channels, out_channels):
+        super().__init__(nn.Conv2d(in_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels),
+                         nn.ReLU(inplace=True))
+
+
+class Attention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.attention = nn.Identity()
+
+
+class DecoderBlock(nn.Module):
+    """smp DecoderBlock: nearest x2, cat[x, skip], Conv2dReLU x 2."""
+
+    def __init__(self, in_channels, skip_channels, out_channels):
+        super().__init__()
+        self.conv1 = Conv2dReLU(in_channels + skip_channels, out_channels)
+        self.attention1 = Attention()
+        self.conv2 = Conv2dReLU(out_channels, out_channels)
+        self.attention2 = Attention()
+
+    def run(self, x: L.Act, skip: t.Optional[L.Act]) -> L.Act:
+        y = L.up2_cat(x, skip)
+        y = L.conv_bn_act(y, self.conv1[0], self.conv1[1], ACT_RELU)
+        return L.conv_bn_act(y, self.conv2[0], self.conv2[1], ACT_RELU)
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        in_ch = [enc[0]] + list(decoder_channels[:-1])
+        skip_ch = enc[1:] + [0]
+        self.center = nn.Identity()
+        self.blocks = nn.ModuleList([DecoderBlock(i, s, o) for i, s, o in zip(in_ch, skip_ch, decoder_channels)])
+        for m in self.modules():  # smp initialize_decoder
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def run(self, feats: t.List[L.Act]) -> L.Act:
+        feats = feats[1:][::-1]
+        x, skips = feats[0], feats[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk.run(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class Activation(nn.Module):
+    def __init__(self, name=None):
+        super().__init__()
+        if name not in (None, "identity"):
+            raise NotImplementedError("only activation=None is used by the reference (basic_model.py:13)")
+        self.activation = nn.Identity()
+
+
+class SegmentationHead(nn.Sequential):
+    """smp SegmentationHead(in, out, kernel_size=3, activation=None, upsampling=1)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, activation=None, upsampling=1):
+        if upsampling != 1:
+            raise NotImplementedError("upsampling > 1 is not used by the reference")
+        conv = nn.Conv2d(in_channels, out_channels, kernel_size, padding=kernel_size // 2)
+        nn.init.xavier_uniform_(conv.weight)  # smp initialize_head
+        nn.init.constant_(conv.bias, 0)
+        super().__init__(conv, nn.Identity(), Activation(activation))
+
+    def run(self, x: L.Act) -> L.Act:
+        return L.conv(x, self[0])
+
+
+class Backbone(nn.Module):
+    """reference vision_mtl/utils/model_utils.py:10-43."""
+
+    def __init__(self, encoder_name: str = "timm-mobilenetv3_large_100", encoder_weights: t.Optional[str] = "imagenet",
+                 decoder_first_channel: int = 256, num_decoder_layers: int = 5, in_channels: int = 3):
+        super().__init__()
+        if encoder_name != "timm-mobilenetv3_large_100":
+            raise NotImplementedError(f"encoder {encoder_name!r}: only timm-mobilenetv3_large_100 is restated")
+        if encoder_weights is not None:
+            raise RuntimeError(
+                f"encoder_weights={encoder_weights!r} needs a network download; pass None (random init) or load a "
+                "state_dict afterwards")
+        self.decoder_channels = [decoder_first_channel // (2 ** i) for i in range(num_decoder_layers)]
+        self.encoder = MobileNetV3Encoder(in_channels, depth=num_decoder_layers)
+        self.decoder = UnetDecoder(self.encoder.out_channels[: num_decoder_layers + 1], self.decoder_channels)
+
+    def run(self, x: L.Act) -> L.Act:
+        return self.decoder.run(self.encoder.run(x))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return L.to_nchw(self.run(L.from_nchw(x)))
+
+
+def get_model_with_dense_preds(segm_classes: int = 10, activation: t.Any = None,
+                               backbone_params: t.Optional[dict] = None) -> nn.Module:
+    """reference vision_mtl/utils/model_utils.py:118-132: Sequential(Backbone, SegmentationHead)."""
+    backbone = Backbone(in_channels=3, **(backbone_params or {}))
+    head = SegmentationHead(backbone.decoder_channels[-1], segm_classes, activation=activation, kernel_size=3)
+    return nn.Sequential(backbone, head)

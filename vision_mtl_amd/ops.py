@@ -38,8 +38,21 @@ def _req(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _k(name, **kw):
+_RECORD = None  # bench.py sets this to a list to capture the GEMM-kernel launches of one step
+
+
+def _k(name, _flop=None, **kw):
+    if _RECORD is not None and _flop is not None:
+        _RECORD.append((name, dict(kw), float(_flop)))  # _flop: algorithmic FLOPs (logical channels)
     lib().callk(name, stream=_stream(), **kw)
+
+
+def _slot(p):
+    """Gradient slot of a parameter inside a dp.FlatArena (None when no arena is attached).  When a
+    slot exists the backward kernels write the parameter gradient straight into it and autograd is
+    told there is nothing to accumulate: gradients of the whole model then form ONE contiguous buffer
+    (one RCCL all-reduce, one fused Adam launch) without per-parameter add / copy kernels."""
+    return None if p is None else getattr(p, "_vmtl_gslot", None)
 
 
 def _empty(shape, like):
@@ -57,22 +70,24 @@ def pack(src, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0):
     return dst
 
 
-def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0):
-    grad = _empty(shape, packed)
+def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None):
+    grad = _empty(shape, packed) if out is None else out
     _k("vmtl_unpack_weights", packed=packed, grad=grad, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st,
        sc=sc, flip=flip)
     return grad
 
 
-def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0):
+def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
     partial = _empty((_reduce_rows(M), Cs), a)
-    out = _empty((1 if reduce_all else C,), a)
+    if out is None:
+        out = _empty((1 if reduce_all else C,), a)
     _k("vmtl_colsum", a=a, b=b, M=M, C=C, Cs=Cs, mode=mode, reduce_all=reduce_all, partial=partial, out=out)
     return out
 
 
-def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0):
-    _k("vmtl_conv2d_fwd", x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
+def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0, cin=None):
+    flop = 2.0 * B * Ho * Wo * Nw * KH * KW * (Cs if cin is None else cin)
+    _k("vmtl_conv2d_fwd", _flop=flop, x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
        Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act=0, shuffle=shuffle)
 
 
@@ -98,9 +113,10 @@ class _Conv2d(torch.autograd.Function):
         if want_stats:
             rows = lib().raw("vmtl_conv2d_stats_rows")(B, Ho, Wo, ldy)
             stats = _empty((rows, 2, ldy), x)
-        _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Cout, Cout, KH, KW, stride, pad)
+        _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Cout, Cout, KH, KW, stride, pad, cin=Cin)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None)
+        ctx.slots = (_slot(weight), _slot(bias))
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -121,14 +137,18 @@ class _Conv2d(torch.autograd.Function):
                 raise NotImplementedError("data gradient of a strided dense conv is not on the hot path")
             wd = pack(weight, 1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, flip=1)
             dx = _empty((B, H, W, Cs), x)
-            _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad)
+            _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=Cout)
         if ctx.needs_input_grad[1]:
             dwp = _empty((Cout, KK * Cs), x)
-            _k("vmtl_conv2d_wgrad", x=x, dy=dy, dwp=dwp, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Cout, KH=KH,
-               KW=KW, stride=stride, pad=pad)
-            dw = unpack(dwp, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK)
+            _k("vmtl_conv2d_wgrad", _flop=2.0 * B * Ho * Wo * Cout * KK * Cin, x=x, dy=dy, dwp=dwp, B=B, H=H, W=W,
+               Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Cout, KH=KH, KW=KW, stride=stride, pad=pad)
+            dw = unpack(dwp, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0])
+            if ctx.slots[0] is not None:
+                dw = None
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, None, B * Ho * Wo, Cout, ldy)
+            db = _colsum(dy, None, B * Ho * Wo, Cout, ldy, out=ctx.slots[1])
+            if ctx.slots[1] is not None:
+                db = None
         return dx, dw, db, None, None, None
 
 
@@ -152,9 +172,10 @@ class _ConvT2x2(torch.autograd.Function):
         ldy = ceil4(Cout)
         wp = pack(weight, 4, Cout, 1, Cin, Cs, 1, 4, 0, Cout * 4)
         y = _empty((B, 2 * H, 2 * W, ldy), x)
-        _conv_launch(x, wp, bias, y, None, B, H, W, Cs, H, W, ldy, 4 * Cout, Cout, 1, 1, 1, 0, shuffle=1)
+        _conv_launch(x, wp, bias, y, None, B, H, W, Cs, H, W, ldy, 4 * Cout, Cout, 1, 1, 1, 0, shuffle=1, cin=Cin)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.slots = (_slot(weight), _slot(bias))
         return y
 
     @staticmethod
@@ -168,14 +189,18 @@ class _ConvT2x2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:  # a 2x2 / stride-2 conv over dy
             wd = pack(weight, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4)
             dx = _empty((B, H, W, Cs), x)
-            _conv_launch(dy, wd, None, dx, None, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, Cin, 2, 2, 2, 0)
+            _conv_launch(dy, wd, None, dx, None, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, Cin, 2, 2, 2, 0, cin=Cout)
         if ctx.needs_input_grad[1]:  # weight gradient of that same conv, with x in the role of its output gradient
             dwp = _empty((Cin, 4 * ldy), x)
-            _k("vmtl_conv2d_wgrad", x=dy, dy=x, dwp=dwp, B=B, H=2 * H, W=2 * W, Cs=ldy, Ho=H, Wo=W, ldy=Cs, Nw=Cin,
-               KH=2, KW=2, stride=2, pad=0)
-            dw = unpack(dwp, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4)
+            _k("vmtl_conv2d_wgrad", _flop=2.0 * B * H * W * Cin * 4 * Cout, x=dy, dy=x, dwp=dwp, B=B, H=2 * H,
+               W=2 * W, Cs=ldy, Ho=H, Wo=W, ldy=Cs, Nw=Cin, KH=2, KW=2, stride=2, pad=0)
+            dw = unpack(dwp, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, out=ctx.slots[0])
+            if ctx.slots[0] is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, None, B * 4 * H * W, Cout, ldy)
+            db = _colsum(dy, None, B * 4 * H * W, Cout, ldy, out=ctx.slots[1])
+            if ctx.slots[1] is not None:
+                db = None
         return dx, dw, db
 
 
@@ -200,6 +225,7 @@ class _DwConv(torch.autograd.Function):
         _k("vmtl_dwconv_fwd", x=x, wp=wp, y=y, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
         ctx.save_for_backward(x, weight, wp)
         ctx.cfg = (stride, pad)
+        ctx.slot = _slot(weight)
         return y
 
     @staticmethod
@@ -217,9 +243,11 @@ class _DwConv(torch.autograd.Function):
                pad=pad)
         if ctx.needs_input_grad[1]:
             partial = _empty((_reduce_rows(B * Ho * Wo), K * K, Cs), x)
-            dw = _empty(weight.shape, x)
+            dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
             _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo,
                K=K, stride=stride, pad=pad)
+            if ctx.slot is not None:
+                dw = None
         return dx, dw, None, None
 
 
@@ -260,6 +288,7 @@ class _BNAct(torch.autograd.Function):
            Cs=Cs, act=act)
         ctx.save_for_backward(x, gamma, beta, mean, invstd, mul)
         ctx.cfg = (C, training, act, res is not None)
+        ctx.slots = (_slot(gamma), _slot(beta))
         return y
 
     @staticmethod
@@ -274,14 +303,15 @@ class _BNAct(torch.autograd.Function):
         partial = sum_dz = sum_dzx = None
         if need_sums or dmul is not None:
             partial = _empty((_reduce_rows(M), 2, Cs), x)
-        if need_sums:
-            sum_dz, sum_dzx = _empty((Cs,), x), _empty((Cs,), x)
+        if need_sums:  # the kernels write exactly C entries: [dbeta | dgamma] may be arena slots
+            sum_dzx = _empty((C,), x) if ctx.slots[0] is None else ctx.slots[0]
+            sum_dz = _empty((C,), x) if ctx.slots[1] is None else ctx.slots[1]
         dx = _empty(x.shape, x)
         _k("vmtl_bn_bwd", x=x, dy=dy, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=mul, dmul=dmul,
            partial=partial, sum_dz=sum_dz, sum_dzx=sum_dzx, dx=dx, M=M, C=C, Cs=Cs, act=act,
            training=1 if training else 0)
-        dgamma = sum_dzx[:C] if need_sums else None
-        dbeta = sum_dz[:C] if need_sums else None
+        dgamma = sum_dzx if (need_sums and ctx.slots[0] is None) else None
+        dbeta = sum_dz if (need_sums and ctx.slots[1] is None) else None
         return (dx, dgamma, dbeta, None, None, None, dmul, dy if has_res else None, None, None, None, None, None,
                 None)
 
@@ -461,6 +491,7 @@ class _Stitch(torch.autograd.Function):
         _k("vmtl_stitch", x=x, w=wview, y=y, M=B * H * W, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
         ctx.save_for_backward(x, weights)
         ctx.cfg = (task, C, channel_wise, off)
+        ctx.slot = _slot(weights)
         return y
 
     @staticmethod
@@ -475,9 +506,12 @@ class _Stitch(torch.autograd.Function):
             dx = _empty(x.shape, x)
             _k("vmtl_stitch", x=dy, w=weights.view(-1)[off:], y=dx, M=M, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(weights)
-            g = _colsum(x, dy, M, C, Cs, mode=1, reduce_all=0 if channel_wise else 1)
-            dw.view(-1)[off:off + g.numel()].copy_(g)
+            n = C if channel_wise else 1
+            if ctx.slot is not None:  # arena slot (off-diagonal entries stay at their initial zero)
+                _colsum(x, dy, M, C, Cs, mode=1, reduce_all=0 if channel_wise else 1, out=ctx.slot.view(-1)[off:off + n])
+            else:
+                dw = torch.zeros_like(weights)
+                _colsum(x, dy, M, C, Cs, mode=1, reduce_all=0 if channel_wise else 1, out=dw.view(-1)[off:off + n])
         return dx, dw, None, None
 
 
