@@ -32,6 +32,13 @@ PEAK_TFLOPS_FP32_MFMA = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 STEP_GFLOP_PER_IMG = {("basic", 128, 256): 33.07, ("basic", 256, 256): 66.14, ("mtan", 256, 256): 201.2}
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def build(args, device):
     from vision_mtl_amd.lit_module import MTLModule
     from vision_mtl_amd.utils.pipeline_utils import build_model
@@ -151,9 +158,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(device)}; building {args.model}")
     model, module = build(args, device)
     arena = dp.FlatArena(model)
     batch = make_batch(args, device, rank)
+    log("model + batch resident")
     import torch.distributed as dist
 
     def step():
@@ -167,11 +176,12 @@ def main():
             arena.adam_step(lr=5e-4, grad_scale=scale)
 
     # eager warm-up (also primes allocator pools and kernel code objects)
-    for _ in range(2):
+    for i in range(2):
         step()
         after_step()
         module.step_outputs["train"]["loss"].clear()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log(f"eager warm-up step {i} done")
 
     graph = None
     if not args.no_graph:
@@ -185,6 +195,7 @@ def main():
             static_loss = step()
         for k in module.step_outputs["train"]:
             module.step_outputs["train"][k].clear()
+        log("hipGraph captured")
 
     def run_step():
         if graph is not None:
@@ -210,6 +221,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float((static_loss if graph is not None else step()).item())
+    log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -232,6 +244,7 @@ def main():
             out["config"]["step_frac_of_fp32_mfma_peak"] = round(tf / PEAK_TFLOPS_FP32_MFMA, 4)
         if not args.no_roofline:
             fam = time_conv_kernels(module, batch)
+            log("per-launch conv timing done")
             ig = fam["vmtl_conv2d_fwd"]
             ach = ig["flop"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_FP32_MFMA,

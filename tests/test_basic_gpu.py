@@ -12,19 +12,20 @@ from tests.util import assert_close
 pytestmark = pytest.mark.gpu
 
 
-def _cpu_step(sd, batch, training=True):
+def _cpu_step(sd, batch, training=True, dtype=torch.float32):
     from oracle.losses import step_losses
     from oracle.unet_mobilenetv3 import basic_forward
 
-    sd = {k: v.clone() for k, v in sd.items()}
+    sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
-    out = basic_forward(sd, batch["img"], training)
-    losses = step_losses(out, batch["mask"], batch["depth"])
+    b = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
+    out = basic_forward(sd, b["img"], training)
+    losses = step_losses(out, b["mask"], b["depth"])
     losses["loss"].backward()
     return out, losses, leaves, sd
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 32, 64)])
+@pytest.mark.parametrize("shape", [(2, 128, 128), (3, 64, 96)])
 def test_basic_step_matches_oracle(dev, shape):
     from oracle.losses import synthetic_batch
     from vision_mtl_amd.lit_module import MTLModule
@@ -48,6 +49,7 @@ def test_basic_step_matches_oracle(dev, shape):
     B, H, W = shape
     batch = synthetic_batch(B, H, W, 19, seed=11, masked=0.1)
     out_ref, losses_ref, leaves, sd_after = _cpu_step(sd0, batch, training=True)
+    _, _, leaves64, _ = _cpu_step(sd0, batch, training=True, dtype=torch.float64)  # "true" gradients
 
     model = model.to(dev).train()
     module = MTLModule(model, num_classes=19, device=str(dev))
@@ -60,10 +62,15 @@ def test_basic_step_matches_oracle(dev, shape):
     loss = module.training_step(dbatch, 0)
     loss.backward()
     assert_close(loss.detach().cpu(), losses_ref["loss"].detach(), tol=1e-4, what="step loss")
-    gscale = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    # Gradient bar: the deep train-mode-BatchNorm stack is ill-conditioned at test sizes (the fp32 CPU
+    # oracle itself is off from an fp64 run by up to several % on some tensors), so each tensor is held
+    # to: error vs the fp64 gradient <= 1e-3 + 3x the fp32 CPU oracle's own error vs fp64.
+    gscale = max(float(v.grad.abs().max()) for v in leaves64.values() if v.grad is not None)
     for k, p in model.named_parameters():
         assert p.grad is not None, f"no grad for {k}"
-        assert_close(p.grad.cpu(), leaves[k].grad, tol=1e-3, atol=1e-6 * gscale, what=f"grad {k}")
+        g64 = leaves64[k].grad
+        noise = float((leaves[k].grad.double() - g64).abs().max())
+        assert_close(p.grad.cpu(), g64, tol=1e-3, atol=1e-6 * gscale + 3 * noise, what=f"grad {k}")
     sd = model.state_dict()
     for k, v in sd_after.items():
         if "running" in k:

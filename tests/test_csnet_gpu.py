@@ -1,0 +1,118 @@
+"""-m gpu: the HIP CSNet (two MobileNetV3-U-Net task networks + 11 cross-stitch sites, leaf-walk
+semantics of reference models/cross_stitch_model.py:102-157) against the straight-line CPU oracle
+(oracle/cross_stitch.py), both stitching modes; plus the CrossStitchLayer against the golden vector
+produced by the reference's own layer."""
+import argparse
+import os
+
+import pytest
+import torch
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("channel_wise", [True, False])
+def test_csnet_step_matches_oracle(dev, channel_wise):
+    from oracle.cross_stitch import csnet_forward
+    from oracle.losses import step_losses, synthetic_batch
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    model = build_model(argparse.Namespace(model_name="csnet", backbone_weights=None,
+                                           channel_wise_stitching=channel_wise), argparse.Namespace(num_classes=19))
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synthetic_batch(2, 128, 128, 19, seed=11, masked=0.1)
+
+    def cpu(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        lv = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+        o = csnet_forward(sd, batch["img"].to(dtype), ["depth", "segm"], True)
+        l = step_losses(o, batch["mask"], batch["depth"].to(dtype))["loss"]
+        l.backward()
+        return o, l, lv
+
+    out_ref, loss_ref, leaves = cpu(torch.float32)
+    _, _, leaves64 = cpu(torch.float64)
+
+    model = model.to(dev).train()
+    module = MTLModule(model, num_classes=19, device=str(dev))
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    out = model(dbatch["img"])
+    assert list(out.keys()) == ["depth", "segm"]
+    for t in out:
+        assert_close(out[t].detach().cpu(), out_ref[t].detach(), tol=1e-4, what=f"csnet out {t}")
+    model.load_state_dict(sd0)
+    loss = module.training_step(dbatch, 0)
+    loss.backward()
+    assert_close(loss.detach().cpu(), loss_ref.detach(), tol=1e-4, what="csnet loss")
+    gscale = max(float(v.grad.abs().max()) for v in leaves64.values() if v.grad is not None)
+    n_none = 0
+    for k, p in model.named_parameters():
+        ref = leaves64[k].grad
+        if ref is None:  # encoder-block BatchNorm parameters never run in the leaf walk
+            assert p.grad is None, f"{k} should not receive a gradient"
+            n_none += 1
+            continue
+        # bar as in test_basic_gpu: vs fp64 truth, 1e-3 + 3x the fp32 CPU oracle's own error
+        noise = float((leaves[k].grad.double() - ref).abs().max())
+        assert_close(p.grad.cpu(), ref, tol=1e-3, atol=1e-6 * gscale + 3 * noise, what=f"grad {k}")
+    assert n_none > 0
+    w = dict(model.named_parameters())["cross_stitch_layers.0_decoder_blocks_0.weights"].grad.cpu()
+    assert float(w[0, 1].abs().max()) == 0.0 and float(w[1, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cw", [0, 1])
+def test_cross_stitch_layer_matches_reference_golden(dev, cw):
+    from vision_mtl_amd.models.cross_stitch_model import CrossStitchLayer
+
+    f = torch.load(os.path.join(G, "components.pt"), weights_only=False)[f"stitch_cw{cw}"]
+    layer = CrossStitchLayer(2, 6 if cw else None).to(dev)
+    with torch.no_grad():
+        layer.weights.copy_(f["w"].to(dev))
+    x = f["x"].to(dev).requires_grad_(True)
+    y = layer(x)
+    y.backward(f["gy"].to(dev))
+    assert_close(y.detach().cpu(), f["y"], tol=1e-6, what="stitch y")
+    assert_close(x.grad.cpu(), f["dx"], tol=1e-6, what="stitch dx")
+    assert_close(layer.weights.grad.cpu(), f["dw"], tol=1e-5, what="stitch dw")
+
+
+def test_golden_losses_and_double_conv(dev):
+    """SILog / CE / DoubleConv / pad-concat against the reference's own outputs (components.pt)."""
+    from vision_mtl_amd import ops
+    from vision_mtl_amd.losses import CrossEntropyLoss, SILogLoss
+    from vision_mtl_amd.utils.model_utils import DoubleConv, concat_slightly_diff_sized_tensors
+
+    fx = torch.load(os.path.join(G, "components.pt"), weights_only=False)
+    for tag in ("valid", "masked"):
+        f = fx[f"silog_{tag}"]
+        z = f["z"].to(dev).requires_grad_(True)
+        l = SILogLoss()(ops.sigmoid(z).permute(0, 2, 3, 1), f["t"].to(dev))
+        l.backward()
+        assert_close(l.detach().cpu(), f["loss"], tol=1e-5, what="silog")
+        assert_close(z.grad.cpu(), f["dz"], tol=1e-4, what="silog grad")
+    for C in (19, 14):
+        f = fx[f"ce_{C}"]
+        z = f["z"].to(dev).requires_grad_(True)
+        l = CrossEntropyLoss()(z, f["t"].to(dev))
+        l.backward()
+        assert_close(l.detach().cpu(), f["loss"], tol=1e-5, what="ce")
+        assert_close(z.grad.cpu(), f["dz"], tol=1e-5, what="ce grad")
+    f = fx["double_conv"]
+    dc = DoubleConv(5, 7)
+    dc.load_state_dict(f["state_dict"])
+    dc = dc.to(dev).train()
+    x = f["x"].to(dev).requires_grad_(True)
+    y = dc(x)
+    y.backward(f["gy"].to(dev))
+    assert_close(y.detach().cpu(), f["y"], tol=1e-4, what="DoubleConv y")
+    assert_close(x.grad.cpu(), f["dx"], tol=1e-3, what="DoubleConv dx")
+    for k, p in dc.named_parameters():
+        assert_close(p.grad.cpu(), f["grads"][k], tol=1e-3, atol=1e-6, what=f"DoubleConv grad {k}")
+    f = fx["pad_concat"]
+    y = concat_slightly_diff_sized_tensors(f["x1"].to(dev), f["x2"].to(dev))
+    assert torch.equal(y.cpu(), f["y"])

@@ -1,0 +1,74 @@
+"""-m "not gpu": the data-parallel layer at world_size 2 over gloo on the CPU.
+Oracle for DP: gradients averaged over N replicas that each see 1/N of the images == gradients of
+one replica on the whole batch, exactly when nothing couples images — eval-mode BatchNorm and the
+CrossEntropy mean (equal shard sizes).  (Train-mode BN statistics and SILog are per-replica, as in
+PyTorch DDP; that is documented in DESIGN.md, not tested for equality.)"""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _state(model):
+    sd = dict(model.named_parameters())
+    sd.update(dict(model.named_buffers()))
+    return sd
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle.losses import synthetic_batch
+    from oracle.mtan import mtan_forward
+    from vision_mtl_amd import dp
+    from vision_mtl_amd.models.mtan_model import MTANMiniUnet
+
+    r, w, _ = dp.init_distributed()
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    torch.manual_seed(5)
+    model = MTANMiniUnet(3, {"depth": 1, "segm": 4}, 8, 4, 2).eval()
+    arena = dp.FlatArena(model)
+    assert arena.flat_grad.numel() == sum(p.numel() for p in model.parameters())
+    assert all(p.data_ptr() >= arena.flat_param.data_ptr() for p in model.parameters())
+    full = synthetic_batch(4, 16, 16, 4, seed=3)
+    shard = dp.shard_batch(full, rank, world)
+    assert shard["img"].shape[0] == 2
+    out = mtan_forward(_state(model), shard["img"], ["depth", "segm"], 2, training=False)
+    F.cross_entropy(out["segm"], shard["mask"]).backward()  # accumulates into the arena views
+    scale = arena.all_reduce_mean()
+    assert scale == 0.5
+    if rank == 0:
+        torch.save((arena.flat_grad * scale).clone(), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_full_batch(tmp_path):
+    tmp = str(tmp_path / "g.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.start_processes(_worker, args=(2, port, tmp), nprocs=2, join=True, start_method="spawn")
+    from oracle.losses import synthetic_batch
+    from oracle.mtan import mtan_forward
+    from vision_mtl_amd import dp
+    from vision_mtl_amd.models.mtan_model import MTANMiniUnet
+
+    torch.manual_seed(5)
+    model = MTANMiniUnet(3, {"depth": 1, "segm": 4}, 8, 4, 2).eval()
+    arena = dp.FlatArena(model)
+    full = synthetic_batch(4, 16, 16, 4, seed=3)
+    out = mtan_forward(_state(model), full["img"], ["depth", "segm"], 2, training=False)
+    F.cross_entropy(out["segm"], full["mask"]).backward()
+    got = torch.load(tmp)
+    ref = arena.flat_grad
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_shard_batch_rejects_ragged():
+    from vision_mtl_amd import dp
+
+    with pytest.raises(ValueError):
+        dp.shard_batch({"img": torch.zeros(5, 3, 4, 4)}, 0, 2)

@@ -30,9 +30,7 @@ class FlatArena:
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
-        dev = params[0].device
-        if dev.type != "cuda":
-            raise RuntimeError("FlatArena: move the model to the GPU first (views would be lost by .to())")
+        dev = params[0].device  # build the arena AFTER model.to(device): .to() would drop the views
         total = sum(p.numel() for p in params)
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
