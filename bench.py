@@ -92,8 +92,11 @@ def cpu_baseline(args):
     """Oracle step (fwd + CE + SILog + bwd, train mode) on the host cores; bounded sample."""
     from oracle.losses import step_losses, synthetic_batch
 
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(avail, 16))
     torch.set_num_threads(threads)
+    log(f"cpu baseline: {threads} threads (affinity {avail}, cpu_count {os.cpu_count()})")
     bs = 8  # BASELINE.json configs[0]: the reference's own CPU-runnable case
     from vision_mtl_amd.utils.pipeline_utils import build_model
 
@@ -124,9 +127,11 @@ def cpu_baseline(args):
                 v.grad = None
         step_losses(run(), batch["mask"], batch["depth"])["loss"].backward()
 
+    t0 = time.perf_counter()
     step()  # warm-up
+    log(f"cpu baseline warm-up step: {time.perf_counter() - t0:.1f}s")
     n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
+    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 20):
         step()
         n += 1
     dt = time.perf_counter() - t0

@@ -39,11 +39,12 @@ const char* vmtl_version(void);
  * vmtl_pack_weights).  The same call with the tap-flipped packing and pad' = K-1-pad is the
  * data gradient of a stride-1 conv.  shuffle=1 scatters rows n=(u*2+v)*Cout+co to output pixel
  * (2h+u, 2w+v) channel co: ConvTranspose2d(k=2,s=2).  stats (optional) receives per-row-block
- * column sums / sums of squares, [vmtl_conv2d_stats_rows()][2][ldy], for BatchNorm. */
+ * column (mean, M2 = sum (v-mean)^2), [vmtl_conv2d_stats_rows()][2][ldy], for BatchNorm. */
 int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
                     int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
                     int KH, int KW, int stride, int pad, int act, int shuffle, void* stream);
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
+int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
 
 /* dwp[n][kk] = sum_m dy[m][n] * gather(x)[m][kk]  (packed layout; zeroed inside the call). */
 int vmtl_conv2d_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cs,
@@ -67,8 +68,8 @@ int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T,
  * replaces nn.BatchNorm2d/ReLU/Sigmoid/mul at utils/model_utils.py:72-76;
  * models/mtan_model.py:67-81,139-167. */
 int vmtl_reduce_rows(int M); /* partial rows used by the two-stage reductions */
-int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv, float eps,
-                  float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
+                  int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                   float* save_mean, float* save_invstd, void* stream);
 int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int C, int Cs, float eps,
                        float* save_mean, float* save_invstd, void* stream);

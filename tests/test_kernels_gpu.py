@@ -57,11 +57,19 @@ def test_conv2d_fwd_bwd(dev, case):
     assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="conv fwd")
     # pad channels must be exactly zero
     assert y[..., Cout:].abs().max().item() == 0.0 if y.shape[-1] > Cout else True
-    # fused column partials == column sums of the output
-    s = stats.sum(0).cpu()
-    yo = yr.detach()
-    assert_close(s[0, :Cout], yo.sum((0, 2, 3)), tol=2e-4, what="conv stats sum")
-    assert_close(s[1, :Cout], (yo * yo).sum((0, 2, 3)), tol=2e-4, what="conv stats sumsq")
+    # fused BatchNorm partials: per row block (mean_b, M2_b); merged (Chan) they give the column mean / variance
+    from vision_mtl_amd._lib import lib
+
+    Ho, Wo = yr.shape[2], yr.shape[3]
+    M = B * Ho * Wo
+    rpb = lib().raw("vmtl_conv2d_stats_block")(B, Ho, Wo, y.shape[-1])
+    st = stats.double().cpu()
+    nb = torch.tensor([max(0, min(rpb, M - b * rpb)) for b in range(st.shape[0])], dtype=torch.float64)[:, None]
+    mean = (nb * st[:, 0]).sum(0) / M
+    var = (st[:, 1] + nb * (st[:, 0] - mean) ** 2).sum(0) / M
+    yo = yr.detach().double()
+    assert_close(mean[:Cout], yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="conv stats mean")
+    assert_close(var[:Cout], yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="conv stats var")
     y.backward(to_dev_nhwc(gy, dev))
     assert_close(wd.grad.cpu(), wr.grad, what="conv wgrad")
     if need_dx:
@@ -176,6 +184,35 @@ def test_bn_act(dev, act, training, shape):
         assert_close(rmd.cpu(), rmr, what="running_mean")
         assert_close(rvd.cpu(), rvr, what="running_var")
         assert int(nbt.item()) == 1
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_bn_large_mean_small_std(dev, fused):
+    """|mean| >> std: E[x^2]-E[x]^2 in fp32 would lose the variance entirely; the (mean, M2) partials
+    merged with Chan's formula must match torch's two-pass statistics.  fused=True takes the partials
+    from the conv epilogue (1x1 conv with a large bias), fused=False from the stand-alone sweep."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    B, C, H, W = 4, 20, 24, 40
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 1, 1, generator=g) * 0.01
+    bias = 300.0 + torch.randn(C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(F.conv2d(xr, w, bias), None, None, gamma, beta, training=True, eps=1e-5))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    if fused:
+        z, stats = ops.conv2d(xd, w.to(dev), bias.to(dev), 1, 0, want_stats=True)
+    else:
+        z, stats = ops.conv2d(xd, w.to(dev), bias.to(dev), 1, 0), None
+    y = ops.bn_act(z, gamma.to(dev), beta.to(dev), rm, rv, nbt, C, True, 0.1, 1e-5, ops.ACT_RELU, stats=stats)
+    assert_close(from_dev_nhwc(y, C), yr.detach(), tol=2e-4, what="bn(large mean) fwd")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=1e-3, what="bn(large mean) dx")
 
 
 def test_plain_activation(dev):

@@ -18,36 +18,98 @@
 extern "C" int vmtl_reduce_rows(int M) { return red_blocks(M); }
 
 // ---------------------------------------------------------------- statistics
-__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const float* __restrict__ x, int M, int Cs,
-                                                               float* partial) {
-  const int CQ = Cs >> 2;
-  column_reduce<2>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * Cs + (size_t)q * 4);
-    acc[0] += v;
-    acc[1] += v * v;
-  });
+// Per-block partial rows are (mean_b, M2_b) over the block's rows, merged by Chan's formula in
+// fp64 (never E[x^2] - E[x]^2).  Each thread accumulates SHIFTED sums around the first value it
+// sees, which keeps fp32 accurate even when |mean| >> std.
+__device__ __forceinline__ void chan_merge(float& n, f32x4& mean, f32x4& m2, float nb, f32x4 mb, f32x4 m2b) {
+  if (nb <= 0.f) return;
+  const float nt = n + nb;
+  const f32x4 d = mb - mean;
+  mean += d * (nb / nt);
+  m2 += m2b + d * d * (n * nb / nt);
+  n = nt;
 }
 
-// mean / invstd from the partial rows; optionally updates running stats the way
-// torch does (momentum, unbiased variance).  save_mean / save_invstd are [Cs].
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, int Cs, float eps,
-                                   float momentum, float* running_mean, float* running_var,
-                                   long long* num_batches_tracked, float* save_mean, float* save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
-  if (c >= Cs) return;
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const float* __restrict__ x, int M, int Cs,
+                                                               float* partial) {
+  __shared__ f32x4 red_mean[RED_THREADS];
+  __shared__ f32x4 red_m2[RED_THREADS];
+  __shared__ float red_n[RED_THREADS];
+  const int CQ = Cs >> 2;
+  const int nblk = gridDim.x;
+  const int rows_per_blk = (M + nblk - 1) / nblk;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int T = rpt * cq;
+    const int t = threadIdx.x;
+    const int q = q0 + t % cq, ro = t / cq;
+    f32x4 K = {0.f, 0.f, 0.f, 0.f}, s1 = K, s2 = K;
+    float n = 0.f;
+    if (t < T)
+      for (int r = r_begin + ro; r < r_end; r += rpt) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * Cs + (size_t)q * 4);
+        if (n == 0.f) K = v;
+        const f32x4 d = v - K;
+        s1 += d;
+        s2 += d * d;
+        n += 1.f;
+      }
+    f32x4 mean = K, m2 = {0.f, 0.f, 0.f, 0.f};
+    if (n > 0.f) {
+      mean = K + s1 * (1.f / n);
+      m2 = s2 - s1 * s1 * (1.f / n);
+    }
+    __syncthreads();
+    red_mean[t] = mean;
+    red_m2[t] = m2;
+    red_n[t] = n;
+    __syncthreads();
+    if (t < cq) {
+      float nt = red_n[t];
+      f32x4 mt = red_mean[t], m2t = red_m2[t];
+      for (int j = 1; j < rpt; ++j) chan_merge(nt, mt, m2t, red_n[t + j * cq], red_mean[t + j * cq], red_m2[t + j * cq]);
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * Cs + (size_t)(q0 + t) * 4) = mt;
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * Cs + (size_t)(q0 + t) * 4) = m2t;
+    }
+  }
+}
+
+// mean / invstd from the (mean_b, M2_b) rows; block b covers rows [b*rows_per_blk, min(M, (b+1)*rows_per_blk)).
+// Optionally updates running stats the way torch does (momentum, unbiased variance).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int rows_per_blk,
+                                                          int M, int C, int Cs, float eps, float momentum,
+                                                          float* running_mean, float* running_var,
+                                                          long long* num_batches_tracked, float* save_mean,
+                                                          float* save_invstd) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;  // one workgroup per storage channel
+  if (c == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
   if (c >= C) {
-    save_mean[c] = 0.f;
-    save_invstd[c] = 0.f;
+    if (threadIdx.x == 0) {
+      save_mean[c] = 0.f;
+      save_invstd[c] = 0.f;
+    }
     return;
   }
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += (double)partial[((size_t)b * 2 + 0) * Cs + c];
-    s2 += (double)partial[((size_t)b * 2 + 1) * Cs + c];
+  auto rows_of = [&](int b) { return max(0, min(rows_per_blk, M - b * rows_per_blk)); };
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x)
+    s += (double)rows_of(b) * (double)partial[((size_t)b * 2 + 0) * Cs + c];
+  const double mean = block_sum(s, sh) / M;
+  double m2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+    const double nb = rows_of(b);
+    if (nb > 0.0) {
+      const double d = (double)partial[((size_t)b * 2 + 0) * Cs + c] - mean;
+      m2 += (double)partial[((size_t)b * 2 + 1) * Cs + c] + nb * d * d;
+    }
   }
-  const double mean = s1 / M;
-  double var = s2 / M - mean * mean;
+  m2 = block_sum(m2, sh);
+  if (threadIdx.x != 0) return;
+  double var = m2 / M;
   if (var < 0.0) var = 0.0;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -67,18 +129,21 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
   save_invstd[c] = c < C ? 1.f / sqrtf(running_var[c] + eps) : 0.f;
 }
 
-extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv, float eps,
-                             float momentum, float* running_mean, float* running_var,
+extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
+                             int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var,
                              long long* num_batches_tracked, float* save_mean, float* save_invstd, void* stream) {
   if (!partial || !save_mean || !save_invstd || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  int nblk = nblk_from_conv;
+  int nblk = nblk_from_conv, rows_per_blk = rows_per_blk_from_conv;
   if (nblk <= 0) {  // partial rows not produced by the conv epilogue: sweep x here
     if (!x) return VMTL_ERR_ARG;
     nblk = red_blocks(M);
+    rows_per_blk = cdiv(M, nblk);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, M, Cs, partial);
+  } else if (rows_per_blk <= 0 || (long long)nblk * rows_per_blk < M) {
+    return VMTL_ERR_ARG;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, st, partial, nblk, M, C, Cs, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cs), dim3(256), 0, st, partial, nblk, rows_per_blk, M, C, Cs, eps,
                      momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
   return vmtl_check_launch();
 }
@@ -180,17 +245,16 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(
 }
 
 // sums the partial rows: dbeta[c] = sum dz, dgamma[c] = sum dz*xhat  (fp64, fixed order)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int Cs, float* sum_dz,
-                                       float* sum_dzx) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;  // exactly C entries are written: the outputs may be slots of a flat gradient arena
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += (double)partial[((size_t)b * 2 + 0) * Cs + c];
-    s2 += (double)partial[((size_t)b * 2 + 1) * Cs + c];
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              int Cs, float* sum_dz, float* sum_dzx) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;  // exactly C workgroups: the outputs may be slots of a flat gradient arena
+  const double s1 = block_rows_sum(partial, nblk, 2, 0, Cs, c, sh);
+  const double s2 = block_rows_sum(partial, nblk, 2, 1, Cs, c, sh);
+  if (threadIdx.x == 0) {
+    sum_dz[c] = (float)s1;
+    sum_dzx[c] = (float)s2;
   }
-  sum_dz[c] = (float)s1;
-  sum_dzx[c] = (float)s2;
 }
 
 // stage 2: dx.  train: gamma*invstd*(dz - sum_dz/M - xhat*sum_dzx/M); eval (or no BN): scale*dz.
@@ -246,8 +310,7 @@ extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, c
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, mean, invstd, gamma, beta,
                        mul, dmul, M, C, Cs, act, partial);
     if (need_sums)
-      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, st, partial, nblk, C, Cs, sum_dz,
-                         sum_dzx);
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx);
   }
   const long long total4 = (long long)M * (Cs >> 2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, st, x, dy, mean, invstd, gamma,
@@ -269,27 +332,18 @@ __global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const float* __rest
   });
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int Cs, int reduce_all,
-                                       float* out) {
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              int Cs, int reduce_all, float* out) {
+  __shared__ double sh[4];
   if (reduce_all) {  // a single scalar: sum over channels too (layer-wise stitch weight gradient)
-    __shared__ double red[128];
-    double s = 0.0;
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-      for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * Cs + c];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 64; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = (float)red[0];
+    double tot = 0.0;
+    for (int c = 0; c < C; ++c) tot += block_rows_sum(partial, nblk, 1, 0, Cs, c, sh);
+    if (threadIdx.x == 0) out[0] = (float)tot;
     return;
   }
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * Cs + c];
-  out[c] = (float)s;
+  const int c = blockIdx.x;
+  const double s = block_rows_sum(partial, nblk, 1, 0, Cs, c, sh);
+  if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 extern "C" int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
@@ -298,7 +352,7 @@ extern "C" int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs,
   hipStream_t st = (hipStream_t)stream;
   const int nblk = red_blocks(M);
   hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, a, b, M, Cs, mode, partial);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(reduce_all ? 1 : cdiv(C, 128)), dim3(128), 0, st, partial, nblk, C,
-                     Cs, reduce_all, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(reduce_all ? 1 : C), dim3(256), 0, st, partial, nblk, C, Cs,
+                     reduce_all, out);
   return vmtl_check_launch();
 }

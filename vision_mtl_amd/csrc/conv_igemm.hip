@@ -31,7 +31,7 @@ struct ConvP {
   const float* wp;    // [Nw][Ktot]
   const float* bias;  // [Nw] or nullptr
   float* y;           // [B][Ho][Wo][ldy]  (or pixel-shuffled, see shuffle)
-  float* stats;       // optional [gridM][2][ldy] per-block column sum / sumsq (or nullptr)
+  float* stats;       // optional [gridM][2][ldy] per-row-block column mean / M2 (or nullptr)
   int B, H, W, Cs;
   int Ho, Wo, ldy;
   int Nw;             // valid weight rows (Cout, or 4*Cout for shuffle)
@@ -176,24 +176,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   // ---- epilogue: bias + activation, zero the pad channels, store ----
   const int hw = p.Ho * p.Wo;
+  float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + l31;
-    const float bv = (p.bias != nullptr && n < p.Nw) ? p.bias[p.shuffle ? n % p.Cout : n] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    bv[j] = (p.bias != nullptr && n < p.Nw) ? p.bias[p.shuffle ? n % p.Cout : n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (m >= p.M) continue;
-        float v = act_fwd(acc[i][j][r] + bv, p.act);
+        float v = act_fwd(acc[i][j][r] + bv[j], p.act);
         if (!p.shuffle) {
           if (n < p.ldy) {
             if (n >= p.Cout) v = 0.f;
             p.y[(size_t)m * p.ldy + n] = v;
-            s1 += v;
-            s2 += v * v;
           }
         } else if (n < p.Nw) {
           const int q = n / p.Cout, co = n - q * p.Cout;
@@ -205,27 +203,69 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
       }
     }
-    if (p.stats != nullptr) {
-      // column partials of this workgroup: the two half-waves hold different rows
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      // reduce over the WAVES_M waves through LDS (As is free after the last barrier)
-      float* red = smem;  // [WAVES_M][2][BN]
-      if (hi == 0) {
-        red[(wm * 2 + 0) * BN + (wn * TN + j) * 32 + l31] = s1;
-        red[(wm * 2 + 1) * BN + (wn * TN + j) * 32 + l31] = s2;
-      }
-    }
   }
+
+  // ---- BatchNorm partials of this row block, straight from the accumulators: per column the
+  // block-local MEAN and M2 = sum (v - mean)^2 (two in-register passes).  The finalize kernel
+  // merges blocks with Chan's parallel-variance formula in fp64, so the variance never goes
+  // through E[x^2] - E[x]^2 (which loses everything when |mean| >> std).
   if (p.stats != nullptr) {
+    float* red = smem;  // [2][WAVES_M][BN]; the staging tiles are dead after the last barrier
+    const int nvalid = min(BM, p.M - m0);
+    auto colval = [&](int i, int j, int r, float& v) -> bool {
+      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int n = n0 + (wn * TN + j) * 32 + l31;
+      v = (n < p.Cout) ? act_fwd(acc[i][j][r] + bv[j], p.act) : 0.f;
+      return m < p.M;
+    };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v;
+          if (colval(i, j, r, v)) s1 += v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      if (hi == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s1;
+    }
     __syncthreads();
-    for (int c = tid; c < 2 * BN; c += 256) {
-      const int which = c / BN, col = c - which * BN;
+    float mean[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) s += smem[(w * 2 + which) * BN + col];
-      const int n = n0 + col;
-      if (n < p.ldy) p.stats[((size_t)tile_m * 2 + which) * p.ldy + n] = s;
+      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + (wn * TN + j) * 32 + l31];
+      mean[j] = s / (float)nvalid;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v;
+          if (colval(i, j, r, v)) s2 += (v - mean[j]) * (v - mean[j]);
+        }
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hi == 0) red[(WAVES_M + wm) * BN + (wn * TN + j) * 32 + l31] = s2;
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      float s = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        s += red[w * BN + c];
+        m2 += red[(WAVES_M + w) * BN + c];
+      }
+      const int n = n0 + c;
+      if (n < p.ldy) {
+        p.stats[((size_t)tile_m * 2 + 0) * p.ldy + n] = s / (float)nvalid;
+        p.stats[((size_t)tile_m * 2 + 1) * p.ldy + n] = m2;
+      }
     }
   }
 }
@@ -408,6 +448,13 @@ extern "C" int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy) {
   int bm, bn;
   conv_pick_tile(B * Ho * Wo, ldy, &bm, &bn);
   return cdiv(B * Ho * Wo, bm);
+}
+
+// output rows covered by each stats row block (the last block may be partial)
+extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
+  int bm, bn;
+  conv_pick_tile(B * Ho * Wo, ldy, &bm, &bn);
+  return bm;
 }
 
 extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,

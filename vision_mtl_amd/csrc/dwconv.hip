@@ -87,14 +87,13 @@ __global__ __launch_bounds__(RED_THREADS) void dwconv_bwd_w_kernel(const float* 
 }
 
 // dw[c][tap] (torch layout (C,1,K,K)) = sum over partial rows, fp64
-__global__ void dwconv_bwd_w_finalize_kernel(const float* __restrict__ partial, int nblk, int KK, int C, int Cs,
-                                             float* dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * KK) return;
+__global__ __launch_bounds__(256) void dwconv_bwd_w_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                                    int KK, int C, int Cs, float* dw) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;  // one workgroup per (channel, tap)
   const int c = i / KK, t = i - c * KK;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[((size_t)b * KK + t) * Cs + c];
-  dw[i] = (float)s;
+  const double s = block_rows_sum(partial, nblk, KK, t, Cs, c, sh);
+  if (threadIdx.x == 0) dw[i] = (float)s;
 }
 
 static inline int dw_grid(long long total4) {
@@ -146,7 +145,7 @@ extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* pa
   else
     hipLaunchKernelGGL((dwconv_bwd_w_kernel<25>), dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
                        stride, pad, M, partial);
-  hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(cdiv(C * K * K, 128)), dim3(128), 0, st, partial, nblk, K * K,
-                     C, Cs, dw);
+  hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(C * K * K), dim3(256), 0, st, partial, nblk, K * K, C, Cs,
+                     dw);
   return vmtl_check_launch();
 }

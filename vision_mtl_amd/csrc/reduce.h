@@ -49,3 +49,31 @@ static inline int red_blocks(int M) {
   return nb;
 }
 
+
+// Sum partial[(b*K + k)*Cs + c] over b = 0..nblk-1 for the workgroup's channel, in fp64, by a
+// 256-thread workgroup (fixed association order -> run-to-run reproducible).  Every thread returns the sum.
+__device__ __forceinline__ double block_rows_sum(const float* __restrict__ partial, int nblk, int K, int k, int Cs,
+                                                 int c, double* sh /* >= 4 doubles */) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += (double)partial[((size_t)b * K + k) * Cs + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+
+// fp64 sum over a 256-thread workgroup; every thread returns the total
+__device__ __forceinline__ double block_sum(double s, double* sh /* >= 4 doubles */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}

@@ -271,9 +271,11 @@ class _BNAct(torch.autograd.Function):
             if training:
                 if stats is not None:
                     partial, nblk = stats, stats.shape[0]
+                    rpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, Cs)
                 else:
-                    partial, nblk = _empty((_reduce_rows(M), 2, Cs), x), 0
-                _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk, eps=eps,
+                    partial, nblk, rpb = _empty((_reduce_rows(M), 2, Cs), x), 0, 0
+                _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk,
+                   rows_per_blk_from_conv=rpb, eps=eps,
                    momentum=momentum, running_mean=running_mean, running_var=running_var, num_batches_tracked=nbt,
                    save_mean=mean, save_invstd=invstd)
             else:
