@@ -82,9 +82,14 @@ def time_conv_kernels(module, batch, reps=3):
         e1.record()
         e1.synchronize()
         f = fam[name]
+        ms = e0.elapsed_time(e1) / reps
         f["flop"] += flop
-        f["ms"] += e0.elapsed_time(e1) / reps
+        f["ms"] += ms
         f["launches"] += 1
+        if os.environ.get("VMTL_CONV_TABLE"):
+            M = kw["B"] * kw["Ho"] * kw["Wo"]
+            log(f"{name[12:]:6s} M={M:8d} N={kw['Nw']:5d} K={kw['KH'] * kw['KW'] * kw['Cs']:6d} "
+                f"k{kw['KH']}s{kw['stride']} {ms * 1e3:9.1f} us {flop / ms / 1e9:7.1f} TF")
     return fam
 
 

@@ -46,8 +46,12 @@ int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
 int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
 
-/* dwp[n][kk] = sum_m dy[m][n] * gather(x)[m][kk]  (packed layout; zeroed inside the call). */
-int vmtl_conv2d_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cs,
+/* slabs[z][n][kk] = sum_{m in pixel slice z} dy[m][n] * gather(x)[m][kk]  (packed layout, plain
+ * stores, no atomics).  splits = vmtl_conv2d_wgrad_splits(B*Ho*Wo, Nw, KH*KW*Cs); the caller
+ * provides splits*Nw*KH*KW*Cs floats and vmtl_unpack_weights(..., nslabs=splits) adds the slabs
+ * in index order while converting to the torch layout (deterministic weight gradient). */
+int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot);
+int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits, int B, int H, int W, int Cs,
                       int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad, void* stream);
 
 /* depthwise KxK (K in {3,5}, stride in {1,2}); wp is packed [K*K][Cs]. */
@@ -62,7 +66,8 @@ int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, floa
 int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
                       long long sr0, long long st, long long sc, int flip, void* stream);
 int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
-                        long long sr1, long long sr0, long long st, long long sc, int flip, void* stream);
+                        long long sr1, long long sr0, long long st, long long sc, int flip, int nslabs,
+                        void* stream);
 
 /* ---- BatchNorm2d (+ activation, gate multiply, residual add) -----------------------------
  * replaces nn.BatchNorm2d/ReLU/Sigmoid/mul at utils/model_utils.py:72-76;

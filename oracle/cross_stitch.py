@@ -47,7 +47,7 @@ def _leaf_block(n: _Net, x, name, spec, c_in):
     return n.conv(y, name + ".conv_pwl")
 
 
-def csnet_forward(sd: dict, x: torch.Tensor, tasks: list, training: bool = True) -> dict:
+def csnet_forward(sd: dict, x: torch.Tensor, tasks: list, training: bool = True, debug=None) -> dict:
     enc = {t: _Net(sd, f"models.{t}.0.encoder.model.", training) for t in tasks}
     dec = {t: _Net(sd, f"models.{t}.0.decoder.", training) for t in tasks}
     f = {t: F.hardswish(enc[t].bn(enc[t].conv(x.clone(), "conv_stem", 2, 1), "bn1")) for t in tasks}
@@ -66,9 +66,14 @@ def csnet_forward(sd: dict, x: torch.Tensor, tasks: list, training: bool = True)
     for i in range(5):
         for t in tasks:
             f[t] = pad_concat(f[t], skips[t][-i - 1]) if i != 4 else F.interpolate(f[t], scale_factor=2, mode="nearest")
+            if debug is not None:
+                debug.append((f"merge{i}", t, f[t].detach()))
         f = _stitch(sd, f"0_decoder_blocks_{i}", f, tasks)
         for t in tasks:
             n = dec[t]
             y = F.relu(n.bn(n.conv(f[t], f"blocks.{i}.conv1.0", 1, 1), f"blocks.{i}.conv1.1"))
             f[t] = F.relu(n.bn(n.conv(y, f"blocks.{i}.conv2.0", 1, 1), f"blocks.{i}.conv2.1"))
+            if debug is not None:
+                debug.append((f"block{i}.conv1", t, y.detach()))
+                debug.append((f"block{i}.conv2", t, f[t].detach()))
     return {t: F.conv2d(f[t], sd[f"models.{t}.1.0.weight"], sd[f"models.{t}.1.0.bias"], padding=1) for t in tasks}

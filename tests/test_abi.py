@@ -23,7 +23,8 @@ def test_host_only_entry_points():
     l = lib()
     assert l.raw("vmtl_reduce_rows")(1) == 1
     assert l.raw("vmtl_reduce_rows")(10 ** 6) == 1024
-    assert l.raw("vmtl_conv2d_stats_rows")(32, 128, 256, 36) == 32 * 128 * 256 // 128
+    assert l.raw("vmtl_conv2d_stats_rows")(32, 128, 256, 36) == 32 * 128 * 256 // l.raw("vmtl_conv2d_stats_block")(32, 128, 256, 36)
+    assert l.raw("vmtl_conv2d_wgrad_splits")(32 * 128 * 256, 33, 612) >= 1
     assert l.raw("vmtl_ce_workspace_bytes")(1 << 20) % 8 == 0
     assert l.raw("vmtl_silog_workspace_bytes")(1 << 20) % 8 == 0
 

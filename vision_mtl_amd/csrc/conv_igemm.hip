@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.
+// Implicit-GEMM convolution on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), NHWC.
 //
 // Replaces the ATen conv2d / conv_transpose2d dispatches reached from
 //   reference vision_mtl/utils/model_utils.py:71,74 (DoubleConv 3x3),
@@ -6,21 +6,23 @@
 //   smp UnetDecoder Conv2dReLU / SegmentationHead and timm pointwise convs
 //   (reference vision_mtl/utils/model_utils.py:25-34, models/basic_model.py:30-41).
 //
-// One kernel serves forward and data-gradient: both are "gather rows of an
-// NHWC tensor per filter tap, contract against a packed [row][tap*Cs+c] weight
-// matrix".  dgrad of a stride-1 conv is the same contraction over dY with the
-// tap-flipped, transposed packing (see pack.hip).  A second kernel computes the
-// weight gradient as a split-K GEMM over pixels.
+// One kernel serves forward and data-gradient: both are "gather rows of an NHWC tensor per
+// filter tap, contract against a packed [row][tap*Cs+c] weight matrix".  dgrad of a stride-1
+// conv is the same contraction over dY with the tap-flipped, transposed packing (pack.hip).
+// A second kernel computes the weight gradient as a deterministic split-K GEMM over pixels.
 //
 // GEMM view (forward):  Y[m][n] = sum_kk  Xcol[m][kk] * Wp[n][kk]
 //   m  = (b, ho, wo)            M    = B*Ho*Wo
 //   kk = tap*Cs + ci            Ktot = KH*KW*Cs   (Cs % 4 == 0, pad channels are 0)
 //   n  = output channel         rows n >= Nw of Wp are treated as 0
 //
-// LDS tiles are [row][BK + 4] with kk contiguous, so one ds_read_b128 gives a
-// lane 4 consecutive kk; lanes 0-31 take kk 0..3 and lanes 32-63 kk 4..7 of each
-// 8-wide k-group and the 4 elements feed 4 MFMAs (k pairs (j, j+4)).  Row stride
-// 36 floats makes those reads conflict-free (9*i mod 16 is a bijection).
+// Why 16x16x4 and not 32x32x2: same MFMA rate (64 FLOP/clk/SIMD), but the model's channel counts
+// are 33/67/135/270/540 (+ concat 151/294/580/1072): 16-granular N tiles (48/80/144/...) keep
+// 70-95 % of the issued MFMAs useful where 32-granular tiles keep ~50 %.
+//
+// LDS tiles are [row][BK + 4] with kk contiguous: one ds_read_b128 gives a lane 4 consecutive kk
+// of its row; lane quarter q = lane>>4 takes kk 4q..4q+3 of each 16-wide k-group and element e
+// feeds MFMA e (k quadruple {e, 4+e, 8+e, 12+e}) - identical mapping for A and B.
 #include "common.h"
 
 #define BK 32
@@ -31,7 +33,7 @@ struct ConvP {
   const float* wp;    // [Nw][Ktot]
   const float* bias;  // [Nw] or nullptr
   float* y;           // [B][Ho][Wo][ldy]  (or pixel-shuffled, see shuffle)
-  float* stats;       // optional [gridM][2][ldy] per-row-block column mean / M2 (or nullptr)
+  float* stats;       // optional [tiles_m][2][ldy] per-row-block column (mean, M2) for BatchNorm
   int B, H, W, Cs;
   int Ho, Wo, ldy;
   int Nw;             // valid weight rows (Cout, or 4*Cout for shuffle)
@@ -43,23 +45,23 @@ struct ConvP {
   int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int TM, int TN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
-  constexpr int TM = BM / WAVES_M / 32;
-  constexpr int TN = BN / WAVES_N / 32;
-  constexpr int RA = BM / 32;  // A rows per thread
-  constexpr int RB = BN / 32;  // B rows per thread
+  constexpr int BM = WAVES_M * TM * 16;
+  constexpr int BN = WAVES_N * TN * 16;
+  constexpr int RA = (BM + 31) / 32;  // A rows per loader thread
+  constexpr int RB = (BN + 31) / 32;  // B rows per loader thread
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                    // [2][BM][LDT]
-  float* Bs = smem + 2 * BM * LDT;     // [2][BN][LDT]
+  float* As = smem;                 // [2][BM][LDT]
+  float* Bs = smem + 2 * BM * LDT;  // [2][BN][LDT]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
   const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int l15 = lane & 15, lq = lane >> 4;
 
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = xcd_remap(blockIdx.x, nwg);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + r0 + 32 * i;
-    if (m < p.M) {
+    if (r0 + 32 * i < BM && m < p.M) {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw;
       const int rem = m - b * hw;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < RB; ++i) {
       const int n = n0 + r0 + 32 * i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kok && n < p.Nw) v = *reinterpret_cast<const f32x4*>(p.wp + (size_t)n * p.Ktot + kk);
+      if (kok && n < p.Nw && r0 + 32 * i < BN) v = *reinterpret_cast<const f32x4*>(p.wp + (size_t)n * p.Ktot + kk);
       rb[i] = v;
     }
     // advance to the next BK chunk
@@ -130,18 +132,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDT + k4 * 4) = ra[i];
+    for (int i = 0; i < RA; ++i)
+      if (BM % 32 == 0 || r0 + 32 * i < BM) *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDT + k4 * 4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDT + k4 * 4) = rb[i];
+    for (int i = 0; i < RB; ++i)
+      if (BN % 32 == 0 || r0 + 32 * i < BN) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDT + k4 * 4) = rb[i];
   };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.Ktot + BK - 1) / BK;
   load_tile();
@@ -152,22 +154,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) load_tile();  // global loads stay in flight under the MFMAs
-    const float* a = As + cur * BM * LDT + (wm * TM * 32 + l31) * LDT + hi * 4;
-    const float* b = Bs + cur * BN * LDT + (wn * TN * 32 + l31) * LDT + hi * 4;
+    const float* a = As + cur * BM * LDT + (wm * TM * 16 + l15) * LDT + lq * 4;
+    const float* b = Bs + cur * BN * LDT + (wn * TN * 16 + l15) * LDT + lq * 4;
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
+    for (int kg = 0; kg < BK / 16; ++kg) {
       f32x4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDT + kg * 8);
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * LDT + kg * 16);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDT + kg * 8);
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 16 * LDT + kg * 16);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -175,17 +177,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 
   // ---- epilogue: bias + activation, zero the pad channels, store ----
+  // C layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int hw = p.Ho * p.Wo;
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + l31;
+    const int n = n0 + (wn * TN + j) * 16 + l15;
     bv[j] = (p.bias != nullptr && n < p.Nw) ? p.bias[p.shuffle ? n % p.Cout : n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * TM + i) * 16 + 4 * lq + r;
         if (m >= p.M) continue;
         float v = act_fwd(acc[i][j][r] + bv[j], p.act);
         if (!p.shuffle) {
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     float* red = smem;  // [2][WAVES_M][BN]; the staging tiles are dead after the last barrier
     const int nvalid = min(BM, p.M - m0);
     auto colval = [&](int i, int j, int r, float& v) -> bool {
-      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int n = n0 + (wn * TN + j) * 32 + l31;
+      const int m = m0 + (wm * TM + i) * 16 + 4 * lq + r;
+      const int n = n0 + (wn * TN + j) * 16 + l15;
       v = (n < p.Cout) ? act_fwd(acc[i][j][r] + bv[j], p.act) : 0.f;
       return m < p.M;
     };
@@ -224,12 +227,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 4; ++r) {
           float v;
           if (colval(i, j, r, v)) s1 += v;
         }
+      s1 += __shfl_xor(s1, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
-      if (hi == 0) red[wm * BN + (wn * TN + j) * 32 + l31] = s1;
+      if (lq == 0) red[wm * BN + (wn * TN + j) * 16 + l15] = s1;
     }
     __syncthreads();
     float mean[TN];
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     for (int j = 0; j < TN; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + (wn * TN + j) * 32 + l31];
+      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + (wn * TN + j) * 16 + l15];
       mean[j] = s / (float)nvalid;
     }
 #pragma unroll
@@ -246,12 +250,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 4; ++r) {
           float v;
           if (colval(i, j, r, v)) s2 += (v - mean[j]) * (v - mean[j]);
         }
+      s2 += __shfl_xor(s2, 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (hi == 0) red[(WAVES_M + wm) * BN + (wn * TN + j) * 32 + l31] = s2;
+      if (lq == 0) red[(WAVES_M + wm) * BN + (wn * TN + j) * 16 + l15] = s2;
     }
     __syncthreads();
     for (int c = tid; c < BN; c += 256) {
@@ -271,15 +276,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 }
 
 // ---------------------------------------------------------------------------
-// weight gradient:  dWp[n][kk] += sum_m dY[m][n] * Xcol[m][kk]   (split over m)
+// weight gradient:  slab[z][n][kk] = sum_{m in pixel slice z} dY[m][n] * Xcol[m][kk]
 // A operand = dY rows (i = n), B operand = im2col(X) (j = kk), k = pixel.
-// LDS tiles are [pixel][channel] exactly as they sit in HBM, so fragment reads
-// are conflict-free ds_read_b32 (32 consecutive floats per half-wave).
+// LDS tiles are [pixel][channel] exactly as they sit in HBM, so fragment reads are
+// conflict-free ds_read_b32 (16 consecutive floats per lane quarter).  Each pixel slice
+// writes its own slab with plain stores; vmtl_unpack_weights sums the slabs in a fixed
+// order (deterministic, no float atomics) while converting to the torch layout.
 // ---------------------------------------------------------------------------
 struct WgradP {
   const float* x;   // [B][H][W][Cs]
   const float* dy;  // [B][Ho][Wo][ldy]
-  float* dwp;       // [Nw][Ktot], zeroed by the caller (this launch accumulates atomically)
+  float* slabs;     // [splits][Nw][Ktot]
   int B, H, W, Cs;
   int Ho, Wo, ldy;
   int Nw;
@@ -289,42 +296,35 @@ struct WgradP {
 };
 
 #define BP 32
+#define WG_BNK 128  // kk columns per workgroup (4 waves x 2 tiles x 16)
 
-template <int BMC, int BNK, int WAVES_M, int WAVES_N>
+template <int TM>  // co rows per workgroup = TM * 16; waves are laid out 1 x 4 along kk
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
-  constexpr int TM = BMC / WAVES_M / 32;
-  constexpr int TN = BNK / WAVES_N / 32;
+  constexpr int TN = 2;
+  constexpr int BMC = TM * 16;
   constexpr int LDY = BMC + 4;
-  constexpr int LDX = BNK + 4;
-  constexpr int YQ = BMC / 4;              // float4 per dY row
-  constexpr int XQ = BNK / 4;              // float4 per X row
-  constexpr int YROWS = 256 / YQ;          // rows covered per pass
-  constexpr int XROWS = 256 / XQ;
-  constexpr int YP = BP / YROWS;           // passes
-  constexpr int XP = BP / XROWS;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  static_assert(YP >= 1 && XP >= 1, "tile too wide for BP");
+  constexpr int LDX = WG_BNK + 4;
+  constexpr int YQ = BMC / 4;                 // float4 per dY row
+  constexpr int YIT = (BP * YQ + 255) / 256;  // loader iterations for the dY tile
+  constexpr int XQ = WG_BNK / 4;              // 32 float4 per X row
+  constexpr int XROWS = 256 / XQ;             // 8 rows per pass
+  constexpr int XP = BP / XROWS;              // 4 passes
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ys = smem;                 // [2][BP][LDY]
   float* Xs = smem + 2 * BP * LDY;  // [2][BP][LDX]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
-  const int l31 = lane & 31, hi = lane >> 5;
+  const int lane = tid & 63, wn = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
 
-  const int kk0 = blockIdx.x * BNK;
+  const int kk0 = blockIdx.x * WG_BNK;
   const int co0 = blockIdx.y * BMC;
   const int p_begin = blockIdx.z * p.chunk;
   const int p_end = min(p.M, p_begin + p.chunk);
-  if (p_begin >= p_end) return;
 
-  // loader geometry: fixed channel column per thread, rows advance with the chunk
-  const int yq = tid % YQ, yr = tid / YQ;
+  // X loader: fixed (tap, ci) column per thread, rows advance with the chunk
   const int xq = tid % XQ, xr = tid / XQ;
-  const int yco = co0 + yq * 4;
-  const bool yok = yco < p.ldy;  // ldy % 4 == 0 -> whole float4 in range
   const int kk = kk0 + xq * 4;
   const bool xok = kk < p.Ktot;
   const int tap = xok ? kk / p.Cs : 0;
@@ -333,14 +333,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int dw = tap % p.KW - p.pad;
   const int hw = p.Ho * p.Wo;
 
-  f32x4 ry[YP], rx[XP];
+  f32x4 ry[YIT], rx[XP];
   auto load_tile = [&](int pp) {
 #pragma unroll
-    for (int i = 0; i < YP; ++i) {
-      const int m = pp + yr + YROWS * i;
+    for (int it = 0; it < YIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / YQ, q = idx - row * YQ;
+      const int m = pp + row, co = co0 + q * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (yok && m < p_end) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + yco);
-      ry[i] = v;
+      if (idx < BP * YQ && m < p_end && co < p.ldy) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + co);
+      ry[it] = v;
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -362,99 +364,119 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     float* ys = Ys + buf * BP * LDY;
     float* xs = Xs + buf * BP * LDX;
 #pragma unroll
-    for (int i = 0; i < YP; ++i) *reinterpret_cast<f32x4*>(ys + (yr + YROWS * i) * LDY + yq * 4) = ry[i];
+    for (int it = 0; it < YIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / YQ, q = idx - row * YQ;
+      if (idx < BP * YQ) *reinterpret_cast<f32x4*>(ys + row * LDY + q * 4) = ry[it];
+    }
 #pragma unroll
     for (int i = 0; i < XP; ++i) *reinterpret_cast<f32x4*>(xs + (xr + XROWS * i) * LDX + xq * 4) = rx[i];
   };
 
-  f32x16 acc[TM][TN];
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  load_tile(p_begin);
-  store_tile(0);
+  if (p_begin < p_end) {
+    load_tile(p_begin);
+    store_tile(0);
+  }
   __syncthreads();
   int cur = 0;
   for (int pp = p_begin; pp < p_end; pp += BP) {
     const bool more = pp + BP < p_end;
     if (more) load_tile(pp + BP);
-    const float* ys = Ys + cur * BP * LDY + hi * LDY + wm * TM * 32 + l31;
-    const float* xs = Xs + cur * BP * LDX + hi * LDX + wn * TN * 32 + l31;
+    const float* ys = Ys + cur * BP * LDY + lq * LDY + l15;
+    const float* xs = Xs + cur * BP * LDX + lq * LDX + wn * TN * 16 + l15;
 #pragma unroll
-    for (int s = 0; s < BP / 2; ++s) {
+    for (int s = 0; s < BP / 4; ++s) {  // 4 pixels per MFMA: lane quarter q supplies pixel 4s+q
       float fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = ys[2 * s * LDY + i * 32];
+      for (int i = 0; i < TM; ++i) fa[i] = ys[4 * s * LDY + i * 16];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = xs[2 * s * LDX + j * 32];
+      for (int j = 0; j < TN; ++j) fb[j] = xs[4 * s * LDX + j * 16];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 
-  // atomics: lanes 0-31 / 32-63 each add 128 contiguous bytes of one dWp row
+  float* slab = p.slabs + (size_t)blockIdx.z * p.Nw * p.Ktot;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = kk0 + (wn * TN + j) * 32 + l31;
+      const int col = kk0 + (wn * TN + j) * 16 + l15;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < p.Nw && col < p.Ktot) atomicAdd(p.dwp + (size_t)row * p.Ktot + col, acc[i][j][r]);
+      for (int r = 0; r < 4; ++r) {
+        const int row = co0 + i * 16 + 4 * lq + r;
+        if (row < p.Nw && col < p.Ktot) slab[(size_t)row * p.Ktot + col] = acc[i][j][r];
       }
     }
 }
 
 // ---------------------------------------------------------------------------
-// host-side launchers
+// host-side tile selection + launchers
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WMV, int WNV>
+struct TileCfg { int bm, bn; };
+// id -> <TM, TN, WAVES_M, WAVES_N>
+//  0 <2,2,4,1> 128x32    1 <2,3,4,1> 128x48    2 <2,4,4,1> 128x64    3 <2,5,4,1> 128x80
+//  4 <4,3,2,2> 128x96    5 <4,4,2,2> 128x128   6 <2,9,4,1> 128x144   7 <4,5,2,2> 128x160
+//  8 <1,2,4,1> 64x32     9 <1,4,4,1> 64x64    10 <2,4,2,2> 64x128   11 <1,9,4,1> 64x144
+static const TileCfg kTiles[] = {{128, 32}, {128, 48}, {128, 64}, {128, 80}, {128, 96}, {128, 128},
+                                 {128, 144}, {128, 160}, {64, 32}, {64, 64}, {64, 128}, {64, 144}};
+
+static int pick_in(int lo, int hi, int ncols) {
+  // minimise the padded column count (issued MFMA work); ties go to the wider tile (more operand reuse)
+  int best = lo;
+  long long best_cost = -1;
+  for (int id = lo; id < hi; ++id) {
+    const long long cost = (long long)cdiv(ncols, kTiles[id].bn) * kTiles[id].bn;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && kTiles[id].bn > kTiles[best].bn)) {
+      best = id;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+static int conv_pick_tile(int M, int ncols) {
+  const int big = pick_in(0, 8, ncols);
+  // too few workgroups for 256 CUs: halve the row block
+  if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_in(8, 12, ncols);
+  return big;
+}
+
+extern "C" int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy) {
+  return cdiv(B * Ho * Wo, kTiles[conv_pick_tile(B * Ho * Wo, ldy)].bm);
+}
+
+// output rows covered by each stats row block (the last block may be partial)
+extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
+  return kTiles[conv_pick_tile(B * Ho * Wo, ldy)].bm;
+}
+
+template <int TM, int TN, int WMV, int WNV>
 static int launch_conv(ConvP& p, hipStream_t st) {
+  constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.shuffle ? p.Nw : p.ldy, BN);
   const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WMV, WNV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WMV, WNV>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   return vmtl_check_launch();
-}
-
-// number of row-blocks the forward kernel will use for a given problem (needed by
-// callers that want the fused BatchNorm column partials: stats is [tiles_m][2][ldy]).
-static void conv_pick_tile(int M, int ncols, int* bm, int* bn) {
-  if (ncols <= 32) { *bm = 128; *bn = 32; }
-  else if (ncols <= 64) { *bm = 128; *bn = 64; }
-  else if (ncols <= 96 || (long long)cdiv(M, 128) * cdiv(ncols, 128) < 384) { *bm = 64; *bn = 64; }
-  else { *bm = 128; *bn = 128; }
-  if (*bm == 128 && *bn == 64 && (long long)cdiv(M, 128) < 256) { *bm = 64; *bn = 64; }
-}
-
-extern "C" int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy) {
-  int bm, bn;
-  conv_pick_tile(B * Ho * Wo, ldy, &bm, &bn);
-  return cdiv(B * Ho * Wo, bm);
-}
-
-// output rows covered by each stats row block (the last block may be partial)
-extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
-  int bm, bn;
-  conv_pick_tile(B * Ho * Wo, ldy, &bm, &bn);
-  return bm;
 }
 
 extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
@@ -465,7 +487,7 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
   if (KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || Nw <= 0 || Cout <= 0 || ldy <= 0) return VMTL_ERR_ARG;
   if (!shuffle && (Cout > ldy || Nw > ldy)) return VMTL_ERR_ARG;
   if (shuffle && (Nw != 4 * Cout || Cout > ldy || stats)) return VMTL_ERR_ARG;
-  // every gathered input coordinate must be expressible; output extent must match the conv arithmetic
+  // output extent must match the conv arithmetic
   if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return VMTL_ERR_ARG;
   if ((long long)B * Ho * Wo > 0x7fffffffLL || (long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
   ConvP p;
@@ -477,51 +499,85 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
   if (shuffle && ldy > Cout &&  // the scatter only writes co < Cout: keep the pad-channel invariant
       hipMemsetAsync(y, 0, (size_t)B * 4 * Ho * Wo * ldy * sizeof(float), st) != hipSuccess)
     return VMTL_ERR_LAUNCH;
-  int bm, bn;
-  conv_pick_tile(p.M, shuffle ? Nw : ldy, &bm, &bn);
-  if (bm == 128 && bn == 32) return launch_conv<128, 32, 4, 1>(p, st);
-  if (bm == 128 && bn == 64) return launch_conv<128, 64, 2, 2>(p, st);
-  if (bm == 64 && bn == 64) return launch_conv<64, 64, 2, 2>(p, st);
-  return launch_conv<128, 128, 2, 2>(p, st);
+  switch (conv_pick_tile(p.M, shuffle ? Nw : ldy)) {
+    case 0: return launch_conv<2, 2, 4, 1>(p, st);
+    case 1: return launch_conv<2, 3, 4, 1>(p, st);
+    case 2: return launch_conv<2, 4, 4, 1>(p, st);
+    case 3: return launch_conv<2, 5, 4, 1>(p, st);
+    case 4: return launch_conv<4, 3, 2, 2>(p, st);
+    case 5: return launch_conv<4, 4, 2, 2>(p, st);
+    case 6: return launch_conv<2, 9, 4, 1>(p, st);
+    case 7: return launch_conv<4, 5, 2, 2>(p, st);
+    case 8: return launch_conv<1, 2, 4, 1>(p, st);
+    case 9: return launch_conv<1, 4, 4, 1>(p, st);
+    case 10: return launch_conv<2, 4, 2, 2>(p, st);
+    default: return launch_conv<1, 9, 4, 1>(p, st);
+  }
 }
 
-template <int BMC, int BNK, int WMV, int WNV>
-static int launch_wgrad(WgradP& p, hipStream_t st) {
-  const int tk = cdiv(p.Ktot, BNK), tc = cdiv(p.Nw, BMC);
-  // split the pixel axis until the grid comfortably fills 256 CUs
-  long long tiles = (long long)tk * tc;
-  int splits = (int)((2048 + tiles - 1) / tiles);
-  const int max_splits = cdiv(p.M, 4 * BP);
-  if (splits > max_splits) splits = max_splits;
+// ---- weight gradient ----
+static int wgrad_rows(int Nw) {  // co rows per workgroup (multiple of 16) minimising padded rows
+  const int cands[] = {16, 32, 48, 64, 80, 144};
+  int best = 16;
+  long long bc = -1;
+  for (int c : cands) {
+    const long long cost = (long long)cdiv(Nw, c) * c;
+    if (bc < 0 || cost < bc || (cost == bc && c > best)) {
+      best = c;
+      bc = cost;
+    }
+  }
+  return best;
+}
+
+// number of pixel slices (= slabs the caller must provide: splits * Nw * Ktot floats)
+extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
+  if (M <= 0 || Nw <= 0 || Ktot <= 0) return 0;
+  const long long tiles = (long long)cdiv(Ktot, WG_BNK) * cdiv(Nw, wgrad_rows(Nw));
+  long long splits = cdivll(1536, tiles);
+  const long long max_by_rows = cdiv(M, 8 * BP);                       // >= 256 pixels per slice
+  const long long max_by_mem = (32ll << 20) / ((long long)Nw * Ktot);  // slabs <= 128 MB
+  if (splits > max_by_rows) splits = max_by_rows;
+  if (splits > max_by_mem) splits = max_by_mem;
   if (splits < 1) splits = 1;
-  int chunk = cdiv(cdiv(p.M, splits), BP) * BP;
-  splits = cdiv(p.M, chunk);
-  p.chunk = chunk;
-  const size_t lds = (size_t)2 * BP * ((BMC + 4) + (BNK + 4)) * sizeof(float);
+  const int chunk = cdiv(cdiv(M, (int)splits), BP) * BP;
+  return cdiv(M, chunk);
+}
+
+template <int TM>
+static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
+  constexpr int BMC = TM * 16;
+  const size_t lds = (size_t)2 * BP * ((BMC + 4) + (WG_BNK + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BMC, BNK, WMV, WNV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<BMC, BNK, WMV, WNV>), dim3(tk, tc, splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM>), dim3(cdiv(p.Ktot, WG_BNK), cdiv(p.Nw, BMC), splits), dim3(256), lds,
+                     st, p);
   return vmtl_check_launch();
 }
 
-extern "C" int vmtl_conv2d_wgrad(const float* x, const float* dy, float* dwp, int B, int H, int W, int Cs,
-                                 int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad,
+extern "C" int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits, int B, int H, int W,
+                                 int Cs, int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad,
                                  void* stream) {
-  if (!x || !dy || !dwp) return VMTL_ERR_ARG;
+  if (!x || !dy || !slabs) return VMTL_ERR_ARG;
   if (Cs <= 0 || (Cs & 3) || (ldy & 3) || Nw <= 0 || Nw > ldy) return VMTL_ERR_ARG;
   if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return VMTL_ERR_ARG;
   if ((long long)B * Ho * Wo > 0x7fffffffLL || (long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
   WgradP p;
-  p.x = x; p.dy = dy; p.dwp = dwp; p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy;
+  p.x = x; p.dy = dy; p.slabs = slabs; p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy;
   p.Nw = Nw; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
+  if (splits != vmtl_conv2d_wgrad_splits(p.M, Nw, p.Ktot)) return VMTL_ERR_ARG;
+  p.chunk = cdiv(cdiv(p.M, splits), BP) * BP;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dwp, 0, (size_t)Nw * p.Ktot * sizeof(float), st);
-  if (e != hipSuccess) return VMTL_ERR_LAUNCH;
-  if (Nw <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
-  if (Nw <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);
-  return launch_wgrad<128, 128, 2, 2>(p, st);
+  switch (wgrad_rows(Nw)) {
+    case 16: return launch_wgrad<1>(p, splits, st);
+    case 32: return launch_wgrad<2>(p, splits, st);
+    case 48: return launch_wgrad<3>(p, splits, st);
+    case 64: return launch_wgrad<4>(p, splits, st);
+    case 80: return launch_wgrad<5>(p, splits, st);
+    default: return launch_wgrad<9>(p, splits, st);
+  }
 }

@@ -31,11 +31,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
   }
 }
 
-// inverse: grad[torch index] = packed[...]; one thread per torch-layout element
+// inverse: grad[torch index] = sum over slabs of packed[slab][...]; one thread per torch-layout
+// element, slabs added in index order (deterministic split-K reduction of the weight gradient)
 __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ packed, float* __restrict__ grad,
                                                      int R1, int R0, int T, int C, int Cs, long long sr1,
                                                      long long sr0, long long st, long long sc, int flip,
-                                                     long long total) {
+                                                     int nslabs, long long slab_stride, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -45,7 +46,10 @@ __global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ p
     const int r0 = (int)(rest % R0);
     const int r1 = (int)(rest / R0);
     const int tp = flip ? T - 1 - t : t;
-    grad[r1 * sr1 + r0 * sr0 + t * st + c * sc] = packed[((size_t)(r1 * R0 + r0) * T + tp) * Cs + c];
+    const float* src = packed + ((size_t)(r1 * R0 + r0) * T + tp) * Cs + c;
+    float s = 0.f;
+    for (int z = 0; z < nslabs; ++z) s += src[(size_t)z * slab_stride];
+    grad[r1 * sr1 + r0 * sr0 + t * st + c * sc] = s;
   }
 }
 
@@ -66,11 +70,12 @@ extern "C" int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, i
 }
 
 extern "C" int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
-                                   long long sr1, long long sr0, long long st, long long sc, int flip, void* stream) {
-  if (!packed || !grad || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs) return VMTL_ERR_ARG;
+                                   long long sr1, long long sr0, long long st, long long sc, int flip, int nslabs,
+                                   void* stream) {
+  if (!packed || !grad || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs || nslabs <= 0) return VMTL_ERR_ARG;
   const long long total = (long long)R1 * R0 * T * C;
   hipLaunchKernelGGL(unpack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, packed, grad, R1, R0, T,
-                     C, Cs, sr1, sr0, st, sc, flip, total);
+                     C, Cs, sr1, sr0, st, sc, flip, nslabs, (long long)R1 * R0 * T * Cs, total);
   return vmtl_check_launch();
 }
 

@@ -85,6 +85,7 @@ class CSNet(nn.Module):
             layers = {n: CrossStitchLayer(self.num_tasks) for n in self.valid_cross_stitch_layer_names}
         self.cross_stitch_layers = nn.ModuleDict(layers)
         self._program = None
+        self.debug_acts = None  # set to a list to capture (op, arg, task, NCHW tensor) after every op (diagnostics)
 
     # ---- reference :159-201
     def consider_encoder_layer_at_idx(self, layer_idx: int) -> bool:
@@ -178,4 +179,6 @@ class CSNet(nn.Module):
                 else:  # conv_bn_relu
                     feats[task] = L.conv_bn_act(f, get_module_by_name(net, arg[0]), get_module_by_name(net, arg[1]),
                                                 ops.ACT_RELU)
+                if self.debug_acts is not None and op in ("merge", "up", "conv_bn_relu"):
+                    self.debug_acts.append((op, arg, task, L.to_nchw(feats[task]).detach().cpu()))
         return {task: L.to_nchw(feats[task]) for task in self.model_names}

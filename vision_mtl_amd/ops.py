@@ -70,11 +70,20 @@ def pack(src, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0):
     return dst
 
 
-def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None):
+def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None, nslabs=1):
     grad = _empty(shape, packed) if out is None else out
     _k("vmtl_unpack_weights", packed=packed, grad=grad, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st,
-       sc=sc, flip=flip)
+       sc=sc, flip=flip, nslabs=nslabs)
     return grad
+
+
+def _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Nw, KH, KW, stride, pad, flop):
+    """Weight-gradient slabs [splits][Nw][KH*KW*Cs] (summed later by unpack)."""
+    splits = lib().raw("vmtl_conv2d_wgrad_splits")(B * Ho * Wo, Nw, KH * KW * Cs)
+    slabs = _empty((splits, Nw, KH * KW * Cs), x)
+    _k("vmtl_conv2d_wgrad", _flop=flop, x=x, dy=dy, slabs=slabs, splits=splits, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo,
+       ldy=ldy, Nw=Nw, KH=KH, KW=KW, stride=stride, pad=pad)
+    return slabs, splits
 
 
 def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
@@ -139,10 +148,9 @@ class _Conv2d(torch.autograd.Function):
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=Cout)
         if ctx.needs_input_grad[1]:
-            dwp = _empty((Cout, KK * Cs), x)
-            _k("vmtl_conv2d_wgrad", _flop=2.0 * B * Ho * Wo * Cout * KK * Cin, x=x, dy=dy, dwp=dwp, B=B, H=H, W=W,
-               Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Cout, KH=KH, KW=KW, stride=stride, pad=pad)
-            dw = unpack(dwp, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0])
+            slabs, ns = _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Cout, KH, KW, stride, pad,
+                               2.0 * B * Ho * Wo * Cout * KK * Cin)
+            dw = unpack(slabs, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns)
             if ctx.slots[0] is not None:
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
@@ -191,10 +199,8 @@ class _ConvT2x2(torch.autograd.Function):
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, Cin, 2, 2, 2, 0, cin=Cout)
         if ctx.needs_input_grad[1]:  # weight gradient of that same conv, with x in the role of its output gradient
-            dwp = _empty((Cin, 4 * ldy), x)
-            _k("vmtl_conv2d_wgrad", _flop=2.0 * B * H * W * Cin * 4 * Cout, x=dy, dy=x, dwp=dwp, B=B, H=2 * H,
-               W=2 * W, Cs=ldy, Ho=H, Wo=W, ldy=Cs, Nw=Cin, KH=2, KW=2, stride=2, pad=0)
-            dw = unpack(dwp, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, out=ctx.slots[0])
+            slabs, ns = _wgrad(dy, x, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, 2, 2, 2, 0, 2.0 * B * H * W * Cin * 4 * Cout)
+            dw = unpack(slabs, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, out=ctx.slots[0], nslabs=ns)
             if ctx.slots[0] is not None:
                 dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
