@@ -120,10 +120,10 @@ int vmtl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cs, vo
  * lit_module.py:31,123 (CrossEntropyLoss); losses.py:14-36 (SILogLoss); lit_module.py:68,112 (MAE). */
 long long vmtl_ce_workspace_bytes(long long P);
 /* element (b,c,hw) of logits / dlogits sits at [b*sb + c*sc + hw*sp] (NCHW: C*HW, HW, 1). */
-int vmtl_ce_fwd(const float* logits, const long long* target, float* lse, float* loss, void* workspace,
-                int B, int HW, int C, long long sb, long long sc, long long sp, void* stream);
-int vmtl_ce_bwd(const float* logits, const long long* target, const float* lse, const float* grad_out,
-                float* dlogits, int B, int HW, int C, long long sb, long long sc, long long sp, void* stream);
+int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void* workspace, int B, int HW,
+                int C, long long sb, long long sc, long long sp, void* stream);
+int vmtl_ce_bwd(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
+                int HW, int C, long long sb, long long sc, long long sp, void* stream);
 long long vmtl_silog_workspace_bytes(long long P);
 int vmtl_silog_fwd(const float* pred, const float* target, float min_depth, float* loss, float* stats,
                    void* workspace, long long P, void* stream);

@@ -67,13 +67,18 @@ def csnet_forward(sd: dict, x: torch.Tensor, tasks: list, training: bool = True,
         for t in tasks:
             f[t] = pad_concat(f[t], skips[t][-i - 1]) if i != 4 else F.interpolate(f[t], scale_factor=2, mode="nearest")
             if debug is not None:
-                debug.append((f"merge{i}", t, f[t].detach()))
+                if f[t].requires_grad:
+                    f[t].retain_grad()
+                debug.append((f"merge{i}", t, f[t]))
         f = _stitch(sd, f"0_decoder_blocks_{i}", f, tasks)
         for t in tasks:
             n = dec[t]
             y = F.relu(n.bn(n.conv(f[t], f"blocks.{i}.conv1.0", 1, 1), f"blocks.{i}.conv1.1"))
             f[t] = F.relu(n.bn(n.conv(y, f"blocks.{i}.conv2.0", 1, 1), f"blocks.{i}.conv2.1"))
             if debug is not None:
-                debug.append((f"block{i}.conv1", t, y.detach()))
-                debug.append((f"block{i}.conv2", t, f[t].detach()))
+                if y.requires_grad:
+                    y.retain_grad()
+                    f[t].retain_grad()
+                debug.append((f"block{i}.conv1", t, y))
+                debug.append((f"block{i}.conv2", t, f[t]))
     return {t: F.conv2d(f[t], sd[f"models.{t}.1.0.weight"], sd[f"models.{t}.1.0.bias"], padding=1) for t in tasks}

@@ -1,13 +1,14 @@
 """-m gpu: the HIP `basic` model (MobileNetV3-Large encoder + U-Net decoder 540..33 + two 3x3 heads)
 against the CPU oracle (oracle/unet_mobilenetv3.py) on identical weights and inputs: outputs and
-step loss within 1e-4, every parameter gradient within 1e-3 of its max magnitude.
+step loss within 1e-4 (max-norm); parameter gradients as accurate (rel-L2 vs an fp64 oracle run) as
+the fp32 CPU oracle itself - the ~50 stacked train-mode BatchNorms make this model ill-conditioned.
 (`basic` is reference-unpinned: smp/timm are not available offline, see the oracle header.)"""
 import argparse
 
 import pytest
 import torch
 
-from tests.util import assert_close
+from tests.util import assert_close, assert_grads_as_good_as_fp32_cpu
 
 pytestmark = pytest.mark.gpu
 
@@ -62,15 +63,11 @@ def test_basic_step_matches_oracle(dev, shape):
     loss = module.training_step(dbatch, 0)
     loss.backward()
     assert_close(loss.detach().cpu(), losses_ref["loss"].detach(), tol=1e-4, what="step loss")
-    # Gradient bar: the deep train-mode-BatchNorm stack is ill-conditioned at test sizes (the fp32 CPU
-    # oracle itself is off from an fp64 run by up to several % on some tensors), so each tensor is held
-    # to: error vs the fp64 gradient <= 1e-3 + 3x the fp32 CPU oracle's own error vs fp64.
-    gscale = max(float(v.grad.abs().max()) for v in leaves64.values() if v.grad is not None)
-    for k, p in model.named_parameters():
-        assert p.grad is not None, f"no grad for {k}"
-        g64 = leaves64[k].grad
-        noise = float((leaves[k].grad.double() - g64).abs().max())
-        assert_close(p.grad.cpu(), g64, tol=1e-3, atol=1e-6 * gscale + 3 * noise, what=f"grad {k}")
+    # gradient bar: see tests/util.py::assert_grads_as_good_as_fp32_cpu
+    hip = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    assert all(g is not None for g in hip.values())
+    assert_grads_as_good_as_fp32_cpu(hip, {k: v.grad for k, v in leaves64.items()},
+                                     {k: v.grad for k, v in leaves.items()})
     sd = model.state_dict()
     for k, v in sd_after.items():
         if "running" in k:

@@ -188,9 +188,11 @@ def test_bn_act(dev, act, training, shape):
 
 @pytest.mark.parametrize("fused", [True, False])
 def test_bn_large_mean_small_std(dev, fused):
-    """|mean| >> std: E[x^2]-E[x]^2 in fp32 would lose the variance entirely; the (mean, M2) partials
-    merged with Chan's formula must match torch's two-pass statistics.  fused=True takes the partials
-    from the conv epilogue (1x1 conv with a large bias), fused=False from the stand-alone sweep."""
+    """|mean| >> std (values ~300, std ~0.05): E[x^2]-E[x]^2 in fp32 would lose the variance entirely;
+    the (mean, M2) partials merged with Chan's formula must match two-pass statistics.  The reference is
+    an fp64 BatchNorm of the SAME conv output (one fp32 ulp of a value near 300 is already ~1e-3 sigma,
+    so comparing two different fp32 convs would test the conv rounding, not the statistics).
+    fused=True takes the partials from the conv epilogue, fused=False from the stand-alone sweep."""
     ops = _ops()
     g = torch.Generator().manual_seed(41)
     B, C, H, W = 4, 20, 24, 40
@@ -198,21 +200,25 @@ def test_bn_large_mean_small_std(dev, fused):
     w = torch.randn(C, C, 1, 1, generator=g) * 0.01
     bias = 300.0 + torch.randn(C, generator=g)
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
-    xr = x.clone().requires_grad_(True)
-    yr = F.relu(F.batch_norm(F.conv2d(xr, w, bias), None, None, gamma, beta, training=True, eps=1e-5))
-    gy = torch.randn(yr.shape, generator=g)
-    yr.backward(gy)
-    xd = to_dev_nhwc(x, dev).requires_grad_(True)
-    nbt = torch.zeros((), dtype=torch.int64, device=dev)
-    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    gy = torch.randn(B, C, H, W, generator=g)
+    xd = to_dev_nhwc(x, dev)
     if fused:
         z, stats = ops.conv2d(xd, w.to(dev), bias.to(dev), 1, 0, want_stats=True)
     else:
         z, stats = ops.conv2d(xd, w.to(dev), bias.to(dev), 1, 0), None
+    z = z.detach().requires_grad_(True)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     y = ops.bn_act(z, gamma.to(dev), beta.to(dev), rm, rv, nbt, C, True, 0.1, 1e-5, ops.ACT_RELU, stats=stats)
-    assert_close(from_dev_nhwc(y, C), yr.detach(), tol=2e-4, what="bn(large mean) fwd")
     y.backward(to_dev_nhwc(gy, dev))
-    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=1e-3, what="bn(large mean) dx")
+    zr = from_dev_nhwc(z.detach(), C).double().requires_grad_(True)
+    rmr, rvr = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    yr = F.relu(F.batch_norm(zr, rmr, rvr, gamma.double(), beta.double(), training=True, eps=1e-5))
+    yr.backward(gy.double())
+    assert_close(from_dev_nhwc(y, C), yr.detach(), tol=1e-4, what="bn(large mean) fwd")
+    assert_close(from_dev_nhwc(z.grad, C), zr.grad, tol=1e-3, what="bn(large mean) dz")
+    assert_close(rm.cpu(), rmr, tol=1e-6, what="running_mean")
+    assert_close(rv.cpu(), rvr, tol=1e-4, what="running_var")
 
 
 def test_plain_activation(dev):
@@ -348,6 +354,24 @@ def test_cross_entropy(dev, C):
     assert abs(l.item() - lr.item()) <= 1e-5 * abs(lr.item())
     assert_close(zd.grad.cpu(), zr.grad, tol=1e-5, what="CE grad")
     assert torch.equal(ops.argmax_channels(zd).cpu(), z.argmax(1))
+
+
+def test_cross_entropy_large_logits(dev):
+    """Logits around +-100 (a net without BatchNorm produces them): the gradient must stay accurate to
+    fp32 rounding of the PROBABILITIES, which needs (z - max) - log(sum), not z - (max + log(sum))."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(37)
+    B, C, H, W = 2, 19, 16, 24
+    z = torch.randn(B, C, H, W, generator=g) * 2 + 120.0 * torch.randn(B, 1, H, W, generator=g)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    zr = z.double().requires_grad_(True)
+    lr = F.cross_entropy(zr, t)
+    lr.backward()
+    zd = z.to(dev).requires_grad_(True)
+    l = ops.cross_entropy(zd, t.to(dev))
+    l.backward()
+    assert abs(l.item() - lr.item()) <= 2e-6 * abs(lr.item())
+    assert_close(zd.grad.cpu(), zr.grad, tol=2e-6, what="CE grad (large logits)")
 
 
 @pytest.mark.parametrize("masked", [False, True])

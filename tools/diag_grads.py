@@ -52,8 +52,19 @@ for k, p in model.named_parameters():
     m = float(ref.abs().max())
     eh = float((p.grad.cpu().double() - ref).abs().max()) / (m + 1e-300)
     ec = float((g32[k].grad.double() - ref).abs().max()) / (m + 1e-300)
-    rows.append((eh, ec, m, k))
-print(f"{'hip_err':>10} {'cpu32_err':>10} {'max|g|':>10}  name   (in parameter order)")
-for eh, ec, m, k in rows:
+    l2h = float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-300))
+    l2c = float((g32[k].grad.double() - ref).norm() / (ref.norm() + 1e-300))
+    rows.append((eh, ec, m, k, l2h, l2c))
+print(f"{'hip_max':>10} {'cpu32_max':>10} {'hip_L2':>10} {'cpu32_L2':>10} {'max|g|':>10}  name   (in parameter order)")
+for eh, ec, m, k, l2h, l2c in rows:
     flag = " <<<" if eh > 1e-3 and eh > 3 * ec else ""
-    print(f"{eh:10.2e} {ec:10.2e} {m:10.2e}  {k}{flag}")
+    print(f"{eh:10.2e} {ec:10.2e} {l2h:10.2e} {l2c:10.2e} {m:10.2e}  {k}{flag}")
+import statistics
+print("SUMMARY worst max-norm hip", max(r[0] for r in rows), "cpu32", max(r[1] for r in rows))
+print("SUMMARY worst L2 hip", max(r[4] for r in rows), "cpu32", max(r[5] for r in rows))
+print("SUMMARY median L2 hip", statistics.median(r[4] for r in rows), "cpu32", statistics.median(r[5] for r in rows))
+# whole-model gradient vector
+num = sum(float((p.grad.cpu().double() - g64[k].grad).pow(2).sum()) for k, p in model.named_parameters() if g64[k].grad is not None)
+den = sum(float(g64[k].grad.pow(2).sum()) for k, p in model.named_parameters() if g64[k].grad is not None)
+num32 = sum(float((g32[k].grad.double() - g64[k].grad).pow(2).sum()) for k in g64 if g64[k].grad is not None)
+print("SUMMARY whole-gradient relative L2: hip", (num / den) ** 0.5, "cpu32", (num32 / den) ** 0.5)

@@ -159,89 +159,134 @@ extern "C" int vmtl_bn_eval_stats(const float* running_mean, const float* runnin
 // ---------------------------------------------------------------- apply
 // y = act(gamma * (x - mean) * invstd + beta) [* mul] [+ res];  pad channels -> 0.
 // gamma/beta may be null (plain activation of x when mean/invstd are null too).
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd,
-                                                       const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ mul,
-                                                       const float* __restrict__ res, float* __restrict__ y,
-                                                       long long total4, int C, int Cs, int act) {
-  const int CQ = Cs >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % CQ);
-    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-    f32x4 o;
+struct BnCoef {
+  f32x4 sc, sh;  // z = x * sc + sh  (sc = 0 on pad channels)
+  f32x4 valid;   // 1 for c < C else 0
+};
+
+__device__ __forceinline__ BnCoef bn_coef(int q, int C, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta) {
+  BnCoef k;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = q * 4 + e;
-      float z = v[e];
-      if (c < C) {
-        if (mean != nullptr) {
-          const float sc = (gamma ? gamma[c] : 1.f) * invstd[c];
-          const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
-          z = z * sc + sh;
-        }
-        o[e] = act_fwd(z, act);
+  for (int e = 0; e < 4; ++e) {
+    const int c = q * 4 + e;
+    float sc = 0.f, sh = 0.f, v = 0.f;
+    if (c < C) {
+      v = 1.f;
+      if (mean != nullptr) {
+        sc = (gamma ? gamma[c] : 1.f) * invstd[c];
+        sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
       } else {
-        o[e] = 0.f;
+        sc = 1.f;
       }
     }
-    if (mul != nullptr) o *= reinterpret_cast<const f32x4*>(mul)[i];
-    if (res != nullptr) o += reinterpret_cast<const f32x4*>(res)[i];
-    reinterpret_cast<f32x4*>(y)[i] = o;
+    k.sc[e] = sc;
+    k.sh[e] = sh;
+    k.valid[e] = v;
   }
+  return k;
 }
 
-static inline int ew_blocks(long long total, int per_block) {
-  long long nb = cdivll(total, per_block);
-  if (nb > 4096) nb = 4096;
-  if (nb < 1) nb = 1;
-  return (int)nb;
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void bn_apply_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ mul,
+                                                               const float* __restrict__ res, float* __restrict__ y,
+                                                               int M, int C, int Cs) {
+  column_sweep(
+      M, Cs >> 2, [&](int q) { return bn_coef(q, C, mean, invstd, gamma, beta); },
+      [&](int r, int q, const BnCoef& k) {
+        const size_t off = (size_t)r * Cs + (size_t)q * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = k.valid[e] != 0.f ? act_fwd(v[e] * k.sc[e] + k.sh[e], ACT) : 0.f;
+        if (mul != nullptr) o *= *reinterpret_cast<const f32x4*>(mul + off);
+        if (res != nullptr) o += *reinterpret_cast<const f32x4*>(res + off);
+        *reinterpret_cast<f32x4*>(y + off) = o;
+      });
 }
+
+#define VMTL_ACT_SWITCH(act, CALL)                   \
+  switch (act) {                                     \
+    case VMTL_ACT_NONE: CALL(VMTL_ACT_NONE); break;   \
+    case VMTL_ACT_RELU: CALL(VMTL_ACT_RELU); break;   \
+    case VMTL_ACT_HSWISH: CALL(VMTL_ACT_HSWISH); break;     \
+    case VMTL_ACT_HSIGMOID: CALL(VMTL_ACT_HSIGMOID); break; \
+    case VMTL_ACT_SIGMOID: CALL(VMTL_ACT_SIGMOID); break;   \
+    default: return VMTL_ERR_ARG;                    \
+  }
 
 extern "C" int vmtl_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, const float* mul, const float* res, float* y, long long M, int C,
                              int Cs, int act, void* stream) {
-  if (!x || !y || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  if (!x || !y || M <= 0 || M > 0x7fffffffLL || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
   if ((mean == nullptr) != (invstd == nullptr)) return VMTL_ERR_ARG;
-  const long long total4 = M * (Cs >> 2);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, mean,
-                     invstd, gamma, beta, mul, res, y, total4, C, Cs, act);
+  const int nb = sweep_blocks(M, Cs);
+#define CALL(A)                                                                                                   \
+  hipLaunchKernelGGL((bn_apply_kernel<A>), dim3(nb), dim3(RED_THREADS), 0, (hipStream_t)stream, x, mean, invstd, \
+                     gamma, beta, mul, res, y, (int)M, C, Cs)
+  VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
   return vmtl_check_launch();
 }
 
 // ---------------------------------------------------------------- backward
+struct BnBwdCoef {
+  f32x4 mean, invstd, gamma, beta, valid;
+  f32x4 c1, c2;  // sum_dz / M, sum_dzx / M (stage 2 only)
+};
+
+__device__ __forceinline__ BnBwdCoef bn_bwd_coef(int q, int C, const float* mean, const float* invstd,
+                                                 const float* gamma, const float* beta, const float* sum_dz,
+                                                 const float* sum_dzx, float invM) {
+  BnBwdCoef k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = q * 4 + e;
+    const bool ok = c < C;
+    k.valid[e] = ok ? 1.f : 0.f;
+    k.mean[e] = (ok && mean) ? mean[c] : 0.f;
+    k.invstd[e] = (ok && mean) ? invstd[c] : 1.f;
+    k.gamma[e] = (ok && gamma) ? gamma[c] : 1.f;
+    k.beta[e] = (ok && beta) ? beta[c] : 0.f;
+    k.c1[e] = (ok && sum_dz) ? sum_dz[c] * invM : 0.f;
+    k.c2[e] = (ok && sum_dzx) ? sum_dzx[c] * invM : 0.f;
+  }
+  return k;
+}
+
 // stage 1: partial sums of dz and dz*xhat per channel (dz = dL/d(pre-activation));
 // also emits dmul = dy * act(z) when a gate operand was used.
+template <int ACT>
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mul, float* __restrict__ dmul, int M, int C, int Cs, int act, float* partial) {
+    const float* __restrict__ mul, float* __restrict__ dmul, int M, int C, int Cs, float* partial) {
   const int CQ = Cs >> 2;
-  column_reduce<2>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
-    const size_t off = (size_t)r * Cs + (size_t)q * 4;
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
-    f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
-    f32x4 mv = {1.f, 1.f, 1.f, 1.f};
-    if (mul != nullptr) mv = *reinterpret_cast<const f32x4*>(mul + off);
-    f32x4 dm = {0.f, 0.f, 0.f, 0.f};
+  column_reduce_init<2>(
+      M, CQ, Cs, partial, [&](int q) { return bn_bwd_coef(q, C, mean, invstd, gamma, beta, nullptr, nullptr, 0.f); },
+      [&](int r, int q, const BnBwdCoef& k, f32x4* acc) {
+        const size_t off = (size_t)r * Cs + (size_t)q * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+        f32x4 mv = {1.f, 1.f, 1.f, 1.f};
+        if (mul != nullptr) mv = *reinterpret_cast<const f32x4*>(mul + off);
+        const f32x4 xh = (xv - k.mean) * k.invstd;
+        const f32x4 z = k.gamma * xh + k.beta;
+        f32x4 dm, dz;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = q * 4 + e;
-      if (c < C) {
-        float xh = xv[e], z = xv[e];
-        if (mean != nullptr) {
-          xh = (xv[e] - mean[c]) * invstd[c];
-          z = (gamma ? gamma[c] : 1.f) * xh + (beta ? beta[c] : 0.f);
+        for (int e = 0; e < 4; ++e) {
+          dm[e] = k.valid[e] * g[e] * act_fwd(z[e], ACT);
+          dz[e] = k.valid[e] * g[e] * mv[e] * act_grad(z[e], ACT);
         }
-        if (mul != nullptr) dm[e] = g[e] * act_fwd(z, act);
-        const float dz = g[e] * mv[e] * act_grad(z, act);
-        acc[0][e] += dz;
-        acc[1][e] += dz * xh;
-      }
-    }
-    if (dmul != nullptr) *reinterpret_cast<f32x4*>(dmul + off) = dm;
-  });
+        acc[0] += dz;
+        acc[1] += dz * xh;
+        if (dmul != nullptr) *reinterpret_cast<f32x4*>(dmul + off) = dm;
+      });
 }
 
 // sums the partial rows: dbeta[c] = sum dz, dgamma[c] = sum dz*xhat  (fp64, fixed order)
@@ -258,40 +303,34 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // stage 2: dx.  train: gamma*invstd*(dz - sum_dz/M - xhat*sum_dzx/M); eval (or no BN): scale*dz.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mul, const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx,
-    float* __restrict__ dx, long long total4, int M, int C, int Cs, int act, int training) {
-  const int CQ = Cs >> 2;
+    float* __restrict__ dx, int M, int C, int Cs, int training) {
   const float invM = 1.f / (float)M;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % CQ);
-    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    f32x4 mv = {1.f, 1.f, 1.f, 1.f};
-    if (mul != nullptr) mv = reinterpret_cast<const f32x4*>(mul)[i];
-    f32x4 o;
+  const bool use_sums = training && mean != nullptr;
+  column_sweep(
+      M, Cs >> 2,
+      [&](int q) {
+        return bn_bwd_coef(q, C, mean, invstd, gamma, beta, use_sums ? sum_dz : nullptr, use_sums ? sum_dzx : nullptr,
+                           invM);
+      },
+      [&](int r, int q, const BnBwdCoef& k) {
+        const size_t off = (size_t)r * Cs + (size_t)q * 4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+        f32x4 mv = {1.f, 1.f, 1.f, 1.f};
+        if (mul != nullptr) mv = *reinterpret_cast<const f32x4*>(mul + off);
+        const f32x4 xh = (xv - k.mean) * k.invstd;
+        const f32x4 z = k.gamma * xh + k.beta;
+        f32x4 dz;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = q * 4 + e;
-      float r = 0.f;
-      if (c < C) {
-        if (mean != nullptr) {
-          const float is = invstd[c], gm = gamma ? gamma[c] : 1.f;
-          const float xh = (xv[e] - mean[c]) * is;
-          const float z = gm * xh + (beta ? beta[c] : 0.f);
-          const float dz = g[e] * mv[e] * act_grad(z, act);
-          r = training ? gm * is * (dz - sum_dz[c] * invM - xh * sum_dzx[c] * invM) : gm * is * dz;
-        } else {
-          r = g[e] * mv[e] * act_grad(xv[e], act);
-        }
-      }
-      o[e] = r;
-    }
-    reinterpret_cast<f32x4*>(dx)[i] = o;
-  }
+        for (int e = 0; e < 4; ++e) dz[e] = k.valid[e] * g[e] * mv[e] * act_grad(z[e], ACT);
+        // without BatchNorm (mean == nullptr) gamma = invstd = 1 and c1 = c2 = 0: dx = dz
+        *reinterpret_cast<f32x4*>(dx + off) = k.gamma * k.invstd * (dz - k.c1 - xh * k.c2);
+      });
 }
 
 // One call = reduce + finalize + apply.  `partial` needs vmtl_reduce_rows(M)*2*Cs floats.
@@ -307,14 +346,20 @@ extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, c
   if (need_sums || dmul != nullptr) {
     if (!partial || (need_sums && (!sum_dz || !sum_dzx))) return VMTL_ERR_ARG;
     const int nblk = red_blocks(M);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, mean, invstd, gamma, beta,
-                       mul, dmul, M, C, Cs, act, partial);
+#define CALL(A)                                                                                                 \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<A>), dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, mean, invstd, gamma, \
+                     beta, mul, dmul, M, C, Cs, partial)
+    VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
     if (need_sums)
       hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx);
   }
-  const long long total4 = (long long)M * (Cs >> 2);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(total4, 256)), dim3(256), 0, st, x, dy, mean, invstd, gamma,
-                     beta, mul, sum_dz, sum_dzx, dx, total4, M, C, Cs, act, training);
+  const int nb = sweep_blocks(M, Cs);
+#define CALL(A)                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<A>), dim3(nb), dim3(RED_THREADS), 0, st, x, dy, mean, invstd, gamma, \
+                     beta, mul, sum_dz, sum_dzx, dx, M, C, Cs, training)
+  VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
   return vmtl_check_launch();
 }
 

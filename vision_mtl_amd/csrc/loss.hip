@@ -27,12 +27,15 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 // Element (b, c, hw) of the logits sits at z[b*sb + c*sc + hw*sp]:
 //   NCHW (the reference's layout at the boundary): sb = C*HW, sc = HW, sp = 1  -> every channel
 //   read of a wave is 256 contiguous bytes;  NHWC: sb = HW*ld, sc = 1, sp = ld.
-// One thread per pixel, online max / sum over the (few) channels in registers.
+// One thread per pixel; the (few) channels are reduced in registers.
+// Numerics: log-softmax is evaluated as (z - max) - log(sum exp(z - max)), subtracting the max FIRST
+// (exact for nearby floats).  Forming lse = max + log(sum) and then z - lse would lose ~ulp(max)
+// per pixel when the logits are large, a systematic error the backward pass of a deep net amplifies.
 __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restrict__ z,
                                                             const long long* __restrict__ tgt,
-                                                            float* __restrict__ lse, double* __restrict__ partial,
-                                                            int* __restrict__ err, long long P, int HW, int C,
-                                                            long long sb, long long sc, long long sp) {
+                                                            double* __restrict__ partial, int* __restrict__ err,
+                                                            long long P, int HW, int C, long long sb, long long sc,
+                                                            long long sp) {
   __shared__ double shd[4];
   double loss = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
@@ -42,11 +45,9 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restr
     for (int c = 1; c < C; ++c) m = fmaxf(m, r[c * sc]);
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(r[c * sc] - m);
-    const float l = m + logf(s);
-    lse[i] = l;
     const long long t = tgt[i];
     if (t < 0 || t >= C) atomicOr(err, 1);  // torch raises on an out-of-range class index
-    else loss += (double)(l - r[t * sc]);
+    else loss += (double)(logf(s) - (r[t * sc] - m));
   }
   const double bs = block_sum_d(loss, shd);
   if (threadIdx.x == 0) partial[blockIdx.x] = bs;
@@ -60,10 +61,10 @@ __global__ void sum_finalize_kernel(const double* __restrict__ partial, int n, d
   if (threadIdx.x == 0) out[0] = (float)(t * scale);
 }
 
-// dz = (softmax(z) - onehot(y)) * gout / P, written with the same strides as z
+// dz = (softmax(z) - onehot(y)) * gout / P, written with the same strides as z.  The softmax is
+// recomputed from the logits (max-subtracted, see above); nothing is saved by the forward pass.
 __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restrict__ z,
                                                             const long long* __restrict__ tgt,
-                                                            const float* __restrict__ lse,
                                                             const float* __restrict__ gout, float* __restrict__ dz,
                                                             long long P, int HW, int C, long long sb, long long sc,
                                                             long long sp) {
@@ -71,9 +72,13 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restr
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / HW, hw = i - b * HW;
     const long long off = b * sb + hw * sp;
-    const float l = lse[i];
+    float m = z[off];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[off + c * sc]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[off + c * sc] - m);
+    const float inv = 1.f / s;
     const int t = (int)tgt[i];
-    for (int c = 0; c < C; ++c) dz[off + c * sc] = (expf(z[off + c * sc] - l) - (c == t ? 1.f : 0.f)) * g;
+    for (int c = 0; c < C; ++c) dz[off + c * sc] = (expf(z[off + c * sc] - m) * inv - (c == t ? 1.f : 0.f)) * g;
   }
 }
 
@@ -88,27 +93,26 @@ extern "C" long long vmtl_ce_workspace_bytes(long long P) { return ((long long)c
 
 // workspace: vmtl_ce_workspace_bytes(P) bytes, 8-byte aligned; the last slot holds the int error flag
 // (non-zero after the call = some target outside [0, C)).
-extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* lse, float* loss, void* workspace,
-                           int B, int HW, int C, long long sb, long long sc, long long sp, void* stream) {
-  if (!logits || !target || !lse || !loss || !workspace || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
+extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void* workspace, int B, int HW,
+                           int C, long long sb, long long sc, long long sp, void* stream) {
+  if (!logits || !target || !loss || !workspace || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)B * HW;
   const int nblk = ce_blocks(P);
   double* partial = (double*)workspace;
   int* err = (int*)(partial + nblk);
   if (hipMemsetAsync(err, 0, sizeof(double), st) != hipSuccess) return VMTL_ERR_LAUNCH;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, lse, partial, err, P, HW, C,
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, err, P, HW, C,
                      sb, sc, sp);
   hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss);
   return vmtl_check_launch();
 }
 
-extern "C" int vmtl_ce_bwd(const float* logits, const long long* target, const float* lse, const float* grad_out,
-                           float* dlogits, int B, int HW, int C, long long sb, long long sc, long long sp,
-                           void* stream) {
-  if (!logits || !target || !lse || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
+extern "C" int vmtl_ce_bwd(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
+                           int HW, int C, long long sb, long long sc, long long sp, void* stream) {
+  if (!logits || !target || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   const long long P = (long long)B * HW;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target, lse,
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target,
                      grad_out, dlogits, P, HW, C, sb, sc, sp);
   return vmtl_check_launch();
 }

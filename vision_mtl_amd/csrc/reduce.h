@@ -42,6 +42,41 @@ __device__ __forceinline__ void column_reduce(int M, int CQ, int Cs, float* part
   }
 }
 
+// column_reduce with a per-thread state built once per column panel (hoists per-channel parameters)
+template <int K, typename Init, typename F>
+__device__ __forceinline__ void column_reduce_init(int M, int CQ, int Cs, float* partial, Init init, F f) {
+  __shared__ f32x4 red[RED_THREADS];
+  const int nblk = gridDim.x;
+  const int rows_per_blk = (M + nblk - 1) / nblk;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int T = rpt * cq;
+    const int t = threadIdx.x;
+    const int q = q0 + t % cq, ro = t / cq;
+    f32x4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+      auto st = init(q);
+      for (int r = r_begin + ro; r < r_end; r += rpt) f(r, q, st, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      __syncthreads();
+      red[t] = acc[k];
+      __syncthreads();
+      if (t < cq) {
+        f32x4 s = red[t];
+        for (int j = 1; j < rpt; ++j) s += red[t + j * cq];
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * K + k) * Cs + (size_t)(q0 + t) * 4) = s;
+      }
+    }
+  }
+}
+
 static inline int red_blocks(int M) {
   int nb = cdiv(M, 64);
   if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
@@ -76,4 +111,35 @@ __device__ __forceinline__ double block_sum(double s, double* sh /* >= 4 doubles
   double t = 0.0;
   for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
   return t;
+}
+
+// Row sweep without a reduction: same thread -> (row offset, float4 column) mapping as
+// column_reduce, so a thread keeps ONE channel quad for all its rows and per-channel parameters
+// are loaded once (init) instead of per element.  Consecutive threads touch consecutive 16-byte
+// chunks of a row (then the next row): fully coalesced for any Cs.
+template <typename Init, typename Body>
+__device__ __forceinline__ void column_sweep(int M, int CQ, Init init, Body body) {
+  const int nblk = gridDim.x;
+  const int rows_per_blk = (M + nblk - 1) / nblk;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int t = threadIdx.x;
+    if (t >= rpt * cq) continue;
+    const int q = q0 + t % cq, ro = t / cq;
+    auto st = init(q);
+    for (int r = r_begin + ro; r < r_end; r += rpt) body(r, q, st);
+  }
+}
+
+static inline int sweep_blocks(long long M, int Cs) {
+  // ~16 float4 per thread per block keeps enough loads in flight without starving the grid
+  long long per_blk = (long long)RED_THREADS * 16 / (Cs >> 2 > 0 ? (Cs >> 2) : 1);
+  if (per_blk < 1) per_blk = 1;
+  long long nb = (M + per_blk - 1) / per_blk;
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  return (int)nb;
 }

@@ -180,5 +180,10 @@ class CSNet(nn.Module):
                     feats[task] = L.conv_bn_act(f, get_module_by_name(net, arg[0]), get_module_by_name(net, arg[1]),
                                                 ops.ACT_RELU)
                 if self.debug_acts is not None and op in ("merge", "up", "conv_bn_relu"):
-                    self.debug_acts.append((op, arg, task, L.to_nchw(feats[task]).detach().cpu()))
+                    rec = [op, arg, task, L.to_nchw(feats[task]).detach().cpu(), None]
+                    if feats[task].t.requires_grad:
+                        C = feats[task].C
+                        feats[task].t.register_hook(
+                            lambda g, rec=rec, C=C: rec.__setitem__(4, g[..., :C].permute(0, 3, 1, 2).detach().cpu()))
+                    self.debug_acts.append(rec)
         return {task: L.to_nchw(feats[task]) for task in self.model_names}

@@ -628,21 +628,20 @@ class _CrossEntropy(torch.autograd.Function):
         if tuple(target.shape) != (B, H, W):
             raise ValueError(f"cross_entropy: target shape {tuple(target.shape)} does not match logits {(B, H, W)}")
         P = B * H * W
-        lse = _empty((P,), logits)
         loss = _empty((), logits)
         ws = torch.empty((lib().raw("vmtl_ce_workspace_bytes")(P) // 8,), dtype=torch.float64, device=logits.device)
-        _k("vmtl_ce_fwd", logits=logits, target=target, lse=lse, loss=loss, workspace=ws, B=B, HW=H * W, C=C,
+        _k("vmtl_ce_fwd", logits=logits, target=target, loss=loss, workspace=ws, B=B, HW=H * W, C=C,
            sb=C * H * W, sc=H * W, sp=1)
-        ctx.save_for_backward(logits, target, lse)
+        ctx.save_for_backward(logits, target)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        logits, target, lse = ctx.saved_tensors
+        logits, target = ctx.saved_tensors
         B, C, H, W = logits.shape
         g = _req(g, "grad_output")
         dl = _empty(logits.shape, logits)
-        _k("vmtl_ce_bwd", logits=logits, target=target, lse=lse, grad_out=g, dlogits=dl, B=B, HW=H * W, C=C,
+        _k("vmtl_ce_bwd", logits=logits, target=target, grad_out=g, dlogits=dl, B=B, HW=H * W, C=C,
            sb=C * H * W, sc=H * W, sp=1)
         return dl, None
 
