@@ -188,10 +188,11 @@ def test_bn_act(dev, act, training, shape):
 
 @pytest.mark.parametrize("fused", [True, False])
 def test_bn_large_mean_small_std(dev, fused):
-    """|mean| >> std (values ~300, std ~0.05): E[x^2]-E[x]^2 in fp32 would lose the variance entirely;
-    the (mean, M2) partials merged with Chan's formula must match two-pass statistics.  The reference is
-    an fp64 BatchNorm of the SAME conv output (one fp32 ulp of a value near 300 is already ~1e-3 sigma,
-    so comparing two different fp32 convs would test the conv rounding, not the statistics).
+    """|mean| >> std (values ~300, std ~0.05): E[x^2]-E[x]^2 in fp32 would lose the variance entirely
+    (x^2 ~ 9e4 has an ulp of 8e-3, the variance is 2e-3); the (mean, M2) partials merged with Chan's
+    formula must match two-pass statistics.  Reference = fp64 BatchNorm of the SAME conv output, no
+    activation (with a mean stored in fp32 the normalised value carries ~3e-4 sigma of representation
+    error, which legitimately flips ReLU masks of values that close to zero).
     fused=True takes the partials from the conv epilogue, fused=False from the stand-alone sweep."""
     ops = _ops()
     g = torch.Generator().manual_seed(41)
@@ -209,16 +210,16 @@ def test_bn_large_mean_small_std(dev, fused):
     z = z.detach().requires_grad_(True)
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    y = ops.bn_act(z, gamma.to(dev), beta.to(dev), rm, rv, nbt, C, True, 0.1, 1e-5, ops.ACT_RELU, stats=stats)
+    y = ops.bn_act(z, gamma.to(dev), beta.to(dev), rm, rv, nbt, C, True, 0.1, 1e-5, ops.ACT_NONE, stats=stats)
     y.backward(to_dev_nhwc(gy, dev))
     zr = from_dev_nhwc(z.detach(), C).double().requires_grad_(True)
     rmr, rvr = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
-    yr = F.relu(F.batch_norm(zr, rmr, rvr, gamma.double(), beta.double(), training=True, eps=1e-5))
+    yr = F.batch_norm(zr, rmr, rvr, gamma.double(), beta.double(), training=True, eps=1e-5)
     yr.backward(gy.double())
-    assert_close(from_dev_nhwc(y, C), yr.detach(), tol=1e-4, what="bn(large mean) fwd")
-    assert_close(from_dev_nhwc(z.grad, C), zr.grad, tol=1e-3, what="bn(large mean) dz")
     assert_close(rm.cpu(), rmr, tol=1e-6, what="running_mean")
-    assert_close(rv.cpu(), rvr, tol=1e-4, what="running_var")
+    assert_close(rv.cpu(), rvr, tol=1e-4, what="running_var (the variance itself)")
+    assert_close(from_dev_nhwc(y, C), yr.detach(), tol=5e-4, what="bn(large mean) fwd")
+    assert_close(from_dev_nhwc(z.grad, C), zr.grad, tol=5e-3, what="bn(large mean) dz")
 
 
 def test_plain_activation(dev):

@@ -1,0 +1,73 @@
+"""Micro-benchmark (GPU box) of the implicit-GEMM kernels on the `basic` decoder shapes at bs 32,
+called through the C ABI.  VMTL_FORCE_TILE=<id> / VMTL_FORCE_WG_SPLITS=<n> override the host heuristics."""
+import argparse
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from vision_mtl_amd._lib import lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--only", default="")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+L = lib()
+st = torch.cuda.current_stream().cuda_stream
+
+
+def c4(c):
+    return (c + 3) // 4 * 4
+
+
+# (name, B, H, W, Cin, Cout, K)
+LAYERS = [("blk0.c1", 32, 8, 16, 1072, 540, 3), ("blk0.c2", 32, 8, 16, 540, 540, 3),
+          ("blk1.c1", 32, 16, 32, 580, 270, 3), ("blk1.c2", 32, 16, 32, 270, 270, 3),
+          ("blk2.c1", 32, 32, 64, 294, 135, 3), ("blk2.c2", 32, 32, 64, 135, 135, 3),
+          ("blk3.c1", 32, 64, 128, 151, 67, 3), ("blk3.c2", 32, 64, 128, 67, 67, 3),
+          ("blk4.c1", 32, 128, 256, 67, 33, 3), ("blk4.c2", 32, 128, 256, 33, 33, 3),
+          ("head20", 32, 128, 256, 33, 20, 3)]
+
+
+def timeit(fn):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / args.reps
+
+
+tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+flops = 0.0
+for name, B, H, W, Cin, Cout, K in LAYERS:
+    if args.only and args.only not in name:
+        continue
+    Cs, ldy, KK = c4(Cin), c4(Cout), K * K
+    x = torch.randn(B, H, W, Cs, device=dev)
+    dy = torch.randn(B, H, W, ldy, device=dev)
+    wp = torch.randn(Cout, KK * Cs, device=dev) * 0.01
+    wd = torch.randn(Cin, KK * ldy, device=dev) * 0.01
+    y = torch.empty(B, H, W, ldy, device=dev)
+    dx = torch.empty(B, H, W, Cs, device=dev)
+    M = B * H * W
+    fl = 2.0 * M * Cout * Cin * KK
+    t_f = timeit(lambda: L.call("vmtl_conv2d_fwd", x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, B, H, W, Cs, H, W,
+                                ldy, Cout, Cout, K, K, 1, K // 2, 0, 0, st))
+    t_d = timeit(lambda: L.call("vmtl_conv2d_fwd", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, H, W, ldy, H,
+                                W, Cs, Cin, Cin, K, K, 1, K // 2, 0, 0, st))
+    S = L.raw("vmtl_conv2d_wgrad_splits")(M, Cout, KK * Cs)
+    slabs = torch.empty(S, Cout, KK * Cs, device=dev)
+    t_w = timeit(lambda: L.call("vmtl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), S, B, H, W, Cs, H, W, ldy,
+                                Cout, K, K, 1, K // 2, st))
+    tot["fwd"] += t_f
+    tot["dgrad"] += t_d
+    tot["wgrad"] += t_w
+    flops += fl
+    print(f"{name:8s} M={M:8d} Cin={Cin:5d} Cout={Cout:4d}  fwd {t_f * 1e3:7.1f} us {fl / t_f / 1e9:6.1f} TF | "
+          f"dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF | wgrad(S={S:3d}) {t_w * 1e3:7.1f} us {fl / t_w / 1e9:6.1f} TF")
+print(f"TOTAL fwd {tot['fwd']:.3f} ms ({flops / tot['fwd'] / 1e9:.1f} TF)  dgrad {tot['dgrad']:.3f} ms ({flops / tot['dgrad'] / 1e9:.1f} TF)"
+      f"  wgrad {tot['wgrad']:.3f} ms ({flops / tot['wgrad'] / 1e9:.1f} TF)  sum {sum(tot.values()):.3f} ms")

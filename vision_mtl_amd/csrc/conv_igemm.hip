@@ -23,6 +23,8 @@
 // LDS tiles are [row][BK + 4] with kk contiguous: one ds_read_b128 gives a lane 4 consecutive kk
 // of its row; lane quarter q = lane>>4 takes kk 4q..4q+3 of each 16-wide k-group and element e
 // feeds MFMA e (k quadruple {e, 4+e, 8+e, 12+e}) - identical mapping for A and B.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define BK 32
@@ -448,6 +450,10 @@ static int pick_in(int lo, int hi, int ncols) {
 }
 
 static int conv_pick_tile(int M, int ncols) {
+  if (const char* f = getenv("VMTL_FORCE_TILE")) {  // tuning aid (tools/bench_conv.py), never set in production
+    const int id = atoi(f);
+    if (id >= 0 && id < 12) return id;
+  }
   const int big = pick_in(0, 8, ncols);
   // too few workgroups for 256 CUs: halve the row block
   if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_in(8, 12, ncols);
@@ -540,6 +546,10 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits > max_by_mem) splits = max_by_mem;
   if (splits < 1) splits = 1;
+  if (const char* f = getenv("VMTL_FORCE_WG_SPLITS")) {  // tuning aid
+    const long long v = atoll(f);
+    if (v >= 1 && v <= max_by_rows) splits = v;
+  }
   const int chunk = cdiv(cdiv(M, (int)splits), BP) * BP;
   return cdiv(M, chunk);
 }
