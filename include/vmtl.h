@@ -65,9 +65,11 @@ int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, floa
 /* torch parameter layout <-> packed GEMM operand (formula in csrc/pack.hip). */
 int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
                       long long sr0, long long st, long long sc, int flip, void* stream);
+int vmtl_pack_weights_slice(const float* src, float* dst, int R0, int T, int C, int group, long long sr0,
+                            long long st, long long sc, int flip, void* stream);
 int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
                         long long sr1, long long sr0, long long st, long long sc, int flip, int nslabs,
-                        void* stream);
+                        long long slab_stride, void* stream); /* slab_stride 0: R1*R0*T*Cs */
 
 /* ---- BatchNorm2d (+ activation, gate multiply, residual add) -----------------------------
  * replaces nn.BatchNorm2d/ReLU/Sigmoid/mul at utils/model_utils.py:72-76;
@@ -113,7 +115,7 @@ int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long t
 /* lit_module.py:137-138 (argmax of softmax == argmax of logits) */
 int vmtl_argmax_channels(const float* z, long long* out, int B, int HW, int C, long long sb, long long sc,
                          long long sp, void* stream);
-int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, void* stream);
+int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, int Cw, void* stream);
 int vmtl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cs, void* stream);
 
 /* ---- losses ------------------------------------------------------------------------------

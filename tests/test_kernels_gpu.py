@@ -129,6 +129,30 @@ def test_dwconv(dev, case):
     assert_close(wd.grad.cpu(), wr.grad, what="dwconv wgrad")
 
 
+def test_dual_head(dev):
+    """Fused segm+depth heads == two separate F.conv2d heads (values and all gradients)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(43)
+    B, Cin, H, W, Ca, Cb = 2, 33, 12, 20, 19, 1
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wa, wb = torch.randn(Ca, Cin, 3, 3, generator=g) * 0.1, torch.randn(Cb, Cin, 3, 3, generator=g) * 0.1
+    ba, bb = torch.randn(Ca, generator=g), torch.randn(Cb, generator=g)
+    ga, gb = torch.randn(B, Ca, H, W, generator=g), torch.randn(B, Cb, H, W, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, wa, ba, wb, bb)]
+    ya, yb = F.conv2d(ref[0], ref[1], ref[2], padding=1), F.conv2d(ref[0], ref[3], ref[4], padding=1)
+    torch.autograd.backward([ya, yb], [ga, gb])
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    d = [t.to(dev).requires_grad_(True) for t in (wa, ba, wb, bb)]
+    oa, ob = ops.dual_head(xd, d[0], d[1], d[2], d[3], pad=1)
+    assert oa.is_contiguous() and ob.is_contiguous() and oa.shape == ya.shape and ob.shape == yb.shape
+    assert_close(oa.detach().cpu(), ya.detach(), what="dual head a")
+    assert_close(ob.detach().cpu(), yb.detach(), what="dual head b")
+    torch.autograd.backward([oa, ob], [ga.to(dev), gb.to(dev)])
+    assert_close(from_dev_nhwc(xd.grad, Cin), ref[0].grad, what="dual head dx")
+    for i, name in enumerate(["wa", "ba", "wb", "bb"]):
+        assert_close(d[i].grad.cpu(), ref[i + 1].grad, what=f"dual head d{name}")
+
+
 ACTS = {"none": lambda t: t, "relu": F.relu, "hardswish": F.hardswish, "hardsigmoid": F.hardsigmoid,
         "sigmoid": torch.sigmoid}
 

@@ -427,21 +427,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 // ---------------------------------------------------------------------------
 // host-side tile selection + launchers
 // ---------------------------------------------------------------------------
-struct TileCfg { int bm, bn; };
+struct TileCfg { int bm, bn; float eff; };
 // id -> <TM, TN, WAVES_M, WAVES_N>
 //  0 <2,2,4,1> 128x32    1 <2,3,4,1> 128x48    2 <2,4,4,1> 128x64    3 <2,5,4,1> 128x80
 //  4 <4,3,2,2> 128x96    5 <4,4,2,2> 128x128   6 <2,9,4,1> 128x144   7 <4,5,2,2> 128x160
 //  8 <1,2,4,1> 64x32     9 <1,4,4,1> 64x64    10 <2,4,2,2> 64x128   11 <1,9,4,1> 64x144
-static const TileCfg kTiles[] = {{128, 32}, {128, 48}, {128, 64}, {128, 80}, {128, 96}, {128, 128},
-                                 {128, 144}, {128, 160}, {64, 32}, {64, 64}, {64, 128}, {64, 144}};
+// eff = measured MFMA-rate of the tile relative to the 144-wide one on MI355X (tools/bench_conv.py):
+// narrow tiles re-stage the A operand more often per MFMA.
+static const TileCfg kTiles[] = {{128, 32, 0.55f}, {128, 48, 0.72f}, {128, 64, 0.80f}, {128, 80, 0.88f},
+                                 {128, 96, 0.92f}, {128, 128, 0.95f}, {128, 144, 1.0f}, {128, 160, 1.0f},
+                                 {64, 32, 0.50f},  {64, 64, 0.85f},  {64, 128, 0.75f},  {64, 144, 1.0f}};
 
 static int pick_in(int lo, int hi, int ncols) {
-  // minimise the padded column count (issued MFMA work); ties go to the wider tile (more operand reuse)
+  // minimise issued MFMA work / tile efficiency = (padded columns) / eff
   int best = lo;
-  long long best_cost = -1;
+  float best_cost = -1.f;
   for (int id = lo; id < hi; ++id) {
-    const long long cost = (long long)cdiv(ncols, kTiles[id].bn) * kTiles[id].bn;
-    if (best_cost < 0 || cost < best_cost || (cost == best_cost && kTiles[id].bn > kTiles[best].bn)) {
+    const float cost = (float)((long long)cdiv(ncols, kTiles[id].bn) * kTiles[id].bn) / kTiles[id].eff;
+    if (best_cost < 0.f || cost < best_cost) {
       best = id;
       best_cost = cost;
     }
@@ -522,14 +525,18 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
 }
 
 // ---- weight gradient ----
-static int wgrad_rows(int Nw) {  // co rows per workgroup (multiple of 16) minimising padded rows
-  const int cands[] = {16, 32, 48, 64, 80, 144};
+static int wgrad_rows(int Nw) {
+  // co rows per workgroup (TM*16).  Cost = padded rows / relative efficiency of that tile height:
+  // a 16- or 32-row tile issues 3-4 LDS reads per 2-4 MFMAs and loses to a taller, slightly more
+  // padded one (measured: Nw=270 as 17x16 rows ran at 42 TF, as 2x144 at ~90 TF).
+  static const int cands[] = {16, 32, 48, 64, 80, 144};
+  static const float eff[] = {0.35f, 0.55f, 0.72f, 0.82f, 0.88f, 1.0f};
   int best = 16;
-  long long bc = -1;
-  for (int c : cands) {
-    const long long cost = (long long)cdiv(Nw, c) * c;
-    if (bc < 0 || cost < bc || (cost == bc && c > best)) {
-      best = c;
+  float bc = -1.f;
+  for (int i = 0; i < 6; ++i) {
+    const float cost = (float)((long long)cdiv(Nw, cands[i]) * cands[i]) / eff[i];
+    if (bc < 0.f || cost < bc) {
+      best = cands[i];
       bc = cost;
     }
   }
@@ -541,7 +548,7 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   if (M <= 0 || Nw <= 0 || Ktot <= 0) return 0;
   const long long tiles = (long long)cdiv(Ktot, WG_BNK) * cdiv(Nw, wgrad_rows(Nw));
   long long splits = cdivll(1536, tiles);
-  const long long max_by_rows = cdiv(M, 8 * BP);                       // >= 256 pixels per slice
+  const long long max_by_rows = cdiv(M, 16 * BP);                      // >= 512 pixels per slice
   const long long max_by_mem = (32ll << 20) / ((long long)Nw * Ktot);  // slabs <= 128 MB
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits > max_by_mem) splits = max_by_mem;

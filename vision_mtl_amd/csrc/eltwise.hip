@@ -427,15 +427,17 @@ extern "C" int vmtl_argmax_channels(const float* z, long long* out, int B, int H
 }
 
 // ------------------------------------------------------------------ boundary layout changes
-// NCHW [B][C][H][W] -> NHWC [B][H][W][Cs] (pad channels zero) and back.
+// NCHW [B][C][H][W] -> NHWC [B][H][W][Cs] and back.  Per pixel the first Cw channels are written
+// (c < C from x, C <= c < Cw zero); Cw == Cs writes whole pixels, Cw < Cs fills a channel slice of a
+// wider tensor (y may point at a channel offset inside the pixel).
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
-                                                           int HW, int Cs, long long total) {
+                                                           int HW, int Cs, int Cw, long long total) {
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % Cs);
-    const long long pix = i / Cs;
+    const int c = (int)(i % Cw);
+    const long long pix = i / Cw;
     const int hw = (int)(pix % HW);
     const long long b = pix / HW;
-    y[i] = c < C ? x[((size_t)b * C + c) * HW + hw] : 0.f;
+    y[(size_t)pix * Cs + c] = c < C ? x[((size_t)b * C + c) * HW + hw] : 0.f;
   }
 }
 
@@ -450,11 +452,11 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
-extern "C" int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, void* stream) {
-  if (!x || !y || C > Cs || B <= 0) return VMTL_ERR_ARG;
-  const long long total = (long long)B * HW * Cs;
+extern "C" int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, int Cw, void* stream) {
+  if (!x || !y || C > Cw || Cw > Cs || B <= 0) return VMTL_ERR_ARG;
+  const long long total = (long long)B * HW * Cw;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cs,
-                     total);
+                     Cw, total);
   return vmtl_check_launch();
 }
 

@@ -31,25 +31,62 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
   }
 }
 
-// inverse: grad[torch index] = sum over slabs of packed[slab][...]; one thread per torch-layout
-// element, slabs added in index order (deterministic split-K reduction of the weight gradient)
-__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ packed, float* __restrict__ grad,
-                                                     int R1, int R0, int T, int C, int Cs, long long sr1,
-                                                     long long sr0, long long st, long long sc, int flip,
-                                                     int nslabs, long long slab_stride, long long total) {
+// writes only channels [0, C) of every `group`-wide tap group (dst may point at a channel offset):
+// lets two weight tensors share one packed operand (fused heads).
+__global__ __launch_bounds__(256) void pack_slice_kernel(const float* __restrict__ src, float* __restrict__ dst, int R0,
+                                                         int T, int C, int group, long long sr0, long long st,
+                                                         long long sc, int flip, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     long long rest = i / C;
-    const int t = (int)(rest % T);
-    rest /= T;
-    const int r0 = (int)(rest % R0);
-    const int r1 = (int)(rest / R0);
-    const int tp = flip ? T - 1 - t : t;
-    const float* src = packed + ((size_t)(r1 * R0 + r0) * T + tp) * Cs + c;
+    const int tp = (int)(rest % T);
+    const int r0 = (int)(rest / T);
+    const int t = flip ? T - 1 - tp : tp;
+    dst[((size_t)r0 * T + tp) * group + c] = src[r0 * sr0 + t * st + c * sc];
+  }
+}
+
+// inverse: grad[torch index] = sum over slabs of packed[slab][...].  A workgroup handles 64
+// consecutive torch-layout elements x 4 slab groups: lane -> element (consecutive lanes read
+// consecutive packed floats when C is the fast axis), wave -> slabs z = wave, wave+4, ...; the four
+// partial sums are added in wave order through LDS, so the split-K reduction of the weight gradient
+// is deterministic.
+__global__ __launch_bounds__(256) void unpack_kernel(const float* __restrict__ packed, float* __restrict__ grad,
+                                                     int R1, int R0, int T, int C, int Cs, long long sr1,
+                                                     long long sr0, long long st, long long sc, int flip,
+                                                     int nslabs, long long slab_stride, long long total) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+    const long long i = base + lane;
     float s = 0.f;
-    for (int z = 0; z < nslabs; ++z) s += src[(size_t)z * slab_stride];
-    grad[r1 * sr1 + r0 * sr0 + t * st + c * sc] = s;
+    long long dst = 0;
+    if (i < total) {
+      const int c = (int)(i % C);
+      long long rest = i / C;
+      const int t = (int)(rest % T);
+      rest /= T;
+      const int r0 = (int)(rest % R0);
+      const int r1 = (int)(rest / R0);
+      const int tp = flip ? T - 1 - t : t;
+      dst = r1 * sr1 + r0 * sr0 + t * st + c * sc;
+      const float* src = packed + ((size_t)(r1 * R0 + r0) * T + tp) * Cs + c;
+      int z = zg;
+      for (; z + 12 < nslabs; z += 16) {  // 4 independent loads in flight
+        const float a0 = src[(size_t)z * slab_stride], a1 = src[(size_t)(z + 4) * slab_stride];
+        const float a2 = src[(size_t)(z + 8) * slab_stride], a3 = src[(size_t)(z + 12) * slab_stride];
+        s += a0;
+        s += a1;
+        s += a2;
+        s += a3;
+      }
+      for (; z < nslabs; z += 4) s += src[(size_t)z * slab_stride];
+    }
+    red[zg][lane] = s;
+    __syncthreads();
+    if (zg == 0 && i < total) grad[dst] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    __syncthreads();
   }
 }
 
@@ -69,13 +106,25 @@ extern "C" int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, i
   return vmtl_check_launch();
 }
 
+extern "C" int vmtl_pack_weights_slice(const float* src, float* dst, int R0, int T, int C, int group, long long sr0,
+                                       long long st, long long sc, int flip, void* stream) {
+  if (!src || !dst || R0 <= 0 || T <= 0 || C <= 0 || C > group) return VMTL_ERR_ARG;
+  const long long total = (long long)R0 * T * C;
+  hipLaunchKernelGGL(pack_slice_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, R0, T, C,
+                     group, sr0, st, sc, flip, total);
+  return vmtl_check_launch();
+}
+
 extern "C" int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
                                    long long sr1, long long sr0, long long st, long long sc, int flip, int nslabs,
-                                   void* stream) {
+                                   long long slab_stride, void* stream) {
   if (!packed || !grad || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs || nslabs <= 0) return VMTL_ERR_ARG;
+  if (slab_stride <= 0) slab_stride = (long long)R1 * R0 * T * Cs;  // slabs hold exactly these rows
   const long long total = (long long)R1 * R0 * T * C;
-  hipLaunchKernelGGL(unpack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, packed, grad, R1, R0, T,
-                     C, Cs, sr1, sr0, st, sc, flip, nslabs, (long long)R1 * R0 * T * Cs, total);
+  long long nb = cdivll(total, 64);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(unpack_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, packed, grad, R1, R0, T, C, Cs,
+                     sr1, sr0, st, sc, flip, nslabs, slab_stride, total);
   return vmtl_check_launch();
 }
 

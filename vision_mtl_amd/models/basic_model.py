@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from .. import layers as L
+from .. import ops
 from .unet_mobilenetv3 import Backbone, SegmentationHead
 
 
@@ -27,8 +28,9 @@ class BasicMTLModel(nn.Module):
 
     def forward(self, x: torch.Tensor) -> t.Dict[str, torch.Tensor]:
         dec = self.backbone.run(L.from_nchw(x))
-        depth = L.to_nchw(self.depth_head.run(dec))
-        segm = L.to_nchw(self.segm_head.run(dec))
+        sh, dh = self.segm_head[0], self.depth_head[0]
+        # both 3x3 heads read the same decoder map: one implicit GEMM with N = C + 1 output channels
+        segm, depth = ops.dual_head(dec.t, sh.weight, sh.bias, dh.weight, dh.bias, pad=sh.padding[0])
         return dict(depth=depth, segm=segm)
 
     @torch.no_grad()

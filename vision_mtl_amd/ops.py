@@ -64,16 +64,16 @@ def _reduce_rows(M: int) -> int:
 
 
 # ----------------------------------------------------------------------------- packing
-def pack(src, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0):
-    dst = _empty((R1 * R0, T * Cs), src)
+def pack(src, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None):
+    dst = _empty((R1 * R0, T * Cs), src) if out is None else out
     _k("vmtl_pack_weights", src=src, dst=dst, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st, sc=sc, flip=flip)
     return dst
 
 
-def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None, nslabs=1):
+def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None, nslabs=1, slab_stride=0):
     grad = _empty(shape, packed) if out is None else out
     _k("vmtl_unpack_weights", packed=packed, grad=grad, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st,
-       sc=sc, flip=flip, nslabs=nslabs)
+       sc=sc, flip=flip, nslabs=nslabs, slab_stride=slab_stride)
     return grad
 
 
@@ -248,7 +248,7 @@ class _DwConv(torch.autograd.Function):
             _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=dx, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride,
                pad=pad)
         if ctx.needs_input_grad[1]:
-            partial = _empty((_reduce_rows(B * Ho * Wo), K * K, Cs), x)
+            partial = _empty((64, K * K, Cs), x)
             dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
             _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo,
                K=K, stride=stride, pad=pad)
@@ -537,7 +537,7 @@ class _ToNHWC(torch.autograd.Function):
         B, C, H, W = x.shape
         Cs = ceil4(C)
         y = _empty((B, H, W, Cs), x)
-        _k("vmtl_nchw_to_nhwc", x=x, y=y, B=B, C=C, HW=H * W, Cs=Cs)
+        _k("vmtl_nchw_to_nhwc", x=x, y=y, B=B, C=C, HW=H * W, Cs=Cs, Cw=Cs)
         ctx.C = C
         return y
 
@@ -571,12 +571,92 @@ class _ToNCHW(torch.autograd.Function):
         dy = _req(dy, "dy")
         B, C, H, W = dy.shape
         dx = _empty((B, H, W, ctx.Cs), dy)
-        _k("vmtl_nchw_to_nhwc", x=dy, y=dx, B=B, C=C, HW=H * W, Cs=ctx.Cs)
+        _k("vmtl_nchw_to_nhwc", x=dy, y=dx, B=B, C=C, HW=H * W, Cs=ctx.Cs, Cw=ctx.Cs)
         return dx, None
 
 
 def to_nchw(x, C):
     return _ToNCHW.apply(x, C)
+
+
+def _copy_vec(src, dst, n):
+    """dst[:n] = src[:n] for small per-channel vectors (the pack kernel in its degenerate 1x1x1 form)."""
+    _k("vmtl_pack_weights", src=src, dst=dst, R1=1, R0=1, T=1, C=n, Cs=n, sr1=0, sr0=0, st=0, sc=1, flip=0)
+
+
+class _DualHead(torch.autograd.Function):
+    """Two KxK heads reading the same feature map (reference models/basic_model.py:30-51: segm_head and
+    depth_head) as ONE implicit GEMM with N = Ca + Cb output channels.  Parameters stay separate torch
+    tensors; outputs are the two contiguous NCHW maps the reference returns."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, pad):
+        x, wa, wb = _req(x, "x"), _req(wa, "weight a"), _req(wb, "weight b")
+        B, H, W, Cs = x.shape
+        Ca, Cin, KH, KW = wa.shape
+        Cb = wb.shape[0]
+        if tuple(wb.shape[1:]) != (Cin, KH, KW) or ceil4(Cin) != Cs or ba is None or bb is None:
+            raise ValueError("dual_head: both heads must share input channels / kernel size and have a bias")
+        N, KK = Ca + Cb, KH * KW
+        ldy, Ktot = ceil4(N), KK * Cs
+        wp = _empty((N, Ktot), x)
+        pack(wa, 1, Ca, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=wp[:Ca])
+        pack(wb, 1, Cb, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=wp[Ca:])
+        bias = _empty((N,), x)
+        _copy_vec(ba, bias, Ca)
+        _copy_vec(bb, bias[Ca:], Cb)
+        y = _empty((B, H, W, ldy), x)
+        _conv_launch(x, wp, bias, y, None, B, H, W, Cs, H, W, ldy, N, N, KH, KW, 1, pad, cin=Cin)
+        oa, ob = _empty((B, Ca, H, W), x), _empty((B, Cb, H, W), x)
+        yf = y.view(-1)
+        _k("vmtl_nhwc_to_nchw", x=yf, y=oa, B=B, C=Ca, HW=H * W, Cs=ldy)
+        _k("vmtl_nhwc_to_nchw", x=yf[Ca:], y=ob, B=B, C=Cb, HW=H * W, Cs=ldy)
+        ctx.save_for_backward(x, wa, wb)
+        ctx.cfg = (pad, ldy)
+        ctx.slots = (_slot(wa), _slot(ba), _slot(wb), _slot(bb))
+        return oa, ob
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        x, wa, wb = ctx.saved_tensors
+        pad, ldy = ctx.cfg
+        B, H, W, Cs = x.shape
+        Ca, Cin, KH, KW = wa.shape
+        Cb = wb.shape[0]
+        N, KK = Ca + Cb, KH * KW
+        ga = torch.zeros((B, Ca, H, W), device=x.device) if ga is None else _req(ga, "grad a")
+        gb = torch.zeros((B, Cb, H, W), device=x.device) if gb is None else _req(gb, "grad b")
+        dy = _empty((B, H, W, ldy), x)
+        dyf = dy.view(-1)
+        _k("vmtl_nchw_to_nhwc", x=ga, y=dyf, B=B, C=Ca, HW=H * W, Cs=ldy, Cw=Ca)
+        _k("vmtl_nchw_to_nhwc", x=gb, y=dyf[Ca:], B=B, C=Cb, HW=H * W, Cs=ldy, Cw=ldy - Ca)  # also zeroes pad lanes
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # one tap-flipped, transposed operand [ci][tap'][co]: head a fills co < Ca and zeroes the rest of
+            # every ldy-wide group, head b then fills co in [Ca, Ca+Cb)
+            wd = pack(wa, 1, Cin, KK, Ca, ldy, 0, KK, 1, Cin * KK, flip=1)
+            _k("vmtl_pack_weights_slice", src=wb, dst=wd.view(-1)[Ca:], R0=Cin, T=KK, C=Cb, group=ldy, sr0=KK, st=1,
+               sc=Cin * KK, flip=1)
+            dx = _empty((B, H, W, Cs), x)
+            _conv_launch(dy, wd, None, dx, None, B, H, W, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=N)
+        slabs, ns = _wgrad(x, dy, B, H, W, Cs, H, W, ldy, N, KH, KW, 1, pad, 2.0 * B * H * W * N * KK * Cin)
+        stride = N * KK * Cs
+        dwa = unpack(slabs, wa.shape, 1, Ca, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns,
+                     slab_stride=stride)
+        dwb = unpack(slabs.view(-1)[Ca * KK * Cs:], wb.shape, 1, Cb, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[2],
+                     nslabs=ns, slab_stride=stride)
+        db = _colsum(dy, None, B * H * W, N, ldy)
+        dba = _empty((Ca,), x) if ctx.slots[1] is None else ctx.slots[1]
+        dbb = _empty((Cb,), x) if ctx.slots[3] is None else ctx.slots[3]
+        _copy_vec(db, dba, Ca)
+        _copy_vec(db[Ca:], dbb, Cb)
+        none_if = lambda g, slot: None if slot is not None else g
+        return (dx, none_if(dwa, ctx.slots[0]), none_if(dba, ctx.slots[1]), none_if(dwb, ctx.slots[2]),
+                none_if(dbb, ctx.slots[3]), None)
+
+
+def dual_head(x, wa, ba, wb, bb, pad=1):
+    return _DualHead.apply(x, wa, ba, wb, bb, pad)
 
 
 class _Sigmoid(torch.autograd.Function):
