@@ -36,7 +36,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
 
 
-def assert_grads_as_good_as_fp32_cpu(named_hip, g64, g32, floor=5e-2, whole_floor=5e-3, factor=3.0):
+def assert_grads_as_good_as_fp32_cpu(named_hip, g64, g32, floor=5e-2, whole_floor=5e-3, factor=4.0):
     """End-to-end gradient bar for the deep ReLU + train-mode-BatchNorm networks.
 
     Measured on the MI355X (tools/diag_*.py): every kernel is accurate to 1e-4..1e-6 in

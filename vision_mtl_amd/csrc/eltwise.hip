@@ -33,71 +33,106 @@ struct CatSrc {
   int oh, ow;      // placement offset of the (upsampled) source inside the destination
 };
 
+// one thread per output float4 (16-byte store); a quad that lies inside one source at a 16-byte
+// aligned channel offset is fetched with one 16-byte load, otherwise element by element
 __global__ __launch_bounds__(256) void concat2_kernel(CatSrc s0, CatSrc s1, float* __restrict__ y, int B, int H,
-                                                      int W, int Cd, long long total) {
-  GRID_STRIDE(i, total) {
-    const int c = (int)(i % Cd);
-    const long long pix = i / Cd;
-    const int w = (int)(pix % W);
-    const int h = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long long)W * H));
-    float v = 0.f;
-    if (c < s0.C + s1.C) {
-      const bool first = c < s0.C;
-      const CatSrc& s = first ? s0 : s1;
-      const int cc = first ? c : c - s0.C;
-      const int hh = h - s.oh, ww = w - s.ow;
-      if (hh >= 0 && ww >= 0 && hh < s.Hs * s.up && ww < s.Ws * s.up) {
-        const int hs = hh / s.up, ws = ww / s.up;
-        v = s.p[((size_t)(b * s.Hs + hs) * s.Ws + ws) * s.Cs + cc];
+                                                      int W, int Cd, long long total4) {
+  const int CQ = Cd >> 2;
+  GRID_STRIDE(i, total4) {
+    const int q = (int)(i % CQ);
+    const unsigned pix = (unsigned)(i / CQ);
+    const unsigned w = pix % (unsigned)W, hb = pix / (unsigned)W;
+    const unsigned h = hb % (unsigned)H, b = hb / (unsigned)H;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = q * 4;
+    // pixel of each source that feeds (h, w), or -1
+    long long p0 = -1, p1 = -1;
+    {
+      const int hh = (int)h - s0.oh, ww = (int)w - s0.ow;
+      if (hh >= 0 && ww >= 0 && hh < s0.Hs * s0.up && ww < s0.Ws * s0.up)
+        p0 = ((long long)b * s0.Hs + hh / s0.up) * s0.Ws + ww / s0.up;
+    }
+    if (s1.C > 0) {
+      const int hh = (int)h - s1.oh, ww = (int)w - s1.ow;
+      if (hh >= 0 && ww >= 0 && hh < s1.Hs * s1.up && ww < s1.Ws * s1.up)
+        p1 = ((long long)b * s1.Hs + hh / s1.up) * s1.Ws + ww / s1.up;
+    }
+    if (c0 + 3 < s0.C) {
+      if (p0 >= 0) o = *reinterpret_cast<const f32x4*>(s0.p + (size_t)p0 * s0.Cs + c0);
+    } else if (c0 >= s0.C && ((c0 - s0.C) & 3) == 0 && c0 - s0.C + 3 < s1.C) {
+      if (p1 >= 0) o = *reinterpret_cast<const f32x4*>(s1.p + (size_t)p1 * s1.Cs + (c0 - s0.C));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        float v = 0.f;
+        if (c < s0.C) {
+          if (p0 >= 0) v = s0.p[(size_t)p0 * s0.Cs + c];
+        } else if (c < s0.C + s1.C) {
+          if (p1 >= 0) v = s1.p[(size_t)p1 * s1.Cs + (c - s0.C)];
+        }
+        o[e] = v;
       }
     }
-    y[i] = v;
+    reinterpret_cast<f32x4*>(y)[i] = o;
   }
 }
 
-// gradient of ONE source: gathers (and 2x2-sums for an upsampled source) its channel slice
+// gradient of ONE source: gathers (and 2x2-sums for an upsampled source) its channel slice;
+// one thread per source float4, 16-byte loads when the slice starts at a multiple of 4 channels
 __global__ __launch_bounds__(256) void concat2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
                                                           int H, int W, int Cd, int c_off, int Hs, int Ws, int C,
-                                                          int Cs, int up, int oh, int ow, long long total) {
-  GRID_STRIDE(i, total) {
-    const int c = (int)(i % Cs);
-    const long long pix = i / Cs;
-    const int ws = (int)(pix % Ws);
-    const int hs = (int)((pix / Ws) % Hs);
-    const int b = (int)(pix / ((long long)Ws * Hs));
-    float v = 0.f;
-    if (c < C) {
+                                                          int Cs, int up, int oh, int ow, long long total4) {
+  const int CQ = Cs >> 2;
+  const bool aligned = (c_off & 3) == 0;
+  GRID_STRIDE(i, total4) {
+    const int q = (int)(i % CQ);
+    const unsigned pix = (unsigned)(i / CQ);
+    const unsigned ws = pix % (unsigned)Ws, hb = pix / (unsigned)Ws;
+    const unsigned hs = hb % (unsigned)Hs, b = hb / (unsigned)Hs;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int c0 = q * 4;
+    if (c0 < C)
       for (int u = 0; u < up; ++u)
         for (int t = 0; t < up; ++t) {
-          const int h = hs * up + u + oh, w = ws * up + t + ow;
-          if (h >= 0 && w >= 0 && h < H && w < W) v += dy[((size_t)(b * H + h) * W + w) * Cd + c_off + c];
+          const int h = (int)hs * up + u + oh, w = (int)ws * up + t + ow;
+          if (h < 0 || w < 0 || h >= H || w >= W) continue;
+          const float* src = dy + ((size_t)((long long)b * H + h) * W + w) * Cd + c_off + c0;
+          if (aligned && c0 + 3 < C) {
+            acc += *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c0 + e < C) acc[e] += src[e];
+          }
         }
-    }
-    dx[i] = v;
+    reinterpret_cast<f32x4*>(dx)[i] = acc;
   }
 }
 
 extern "C" int vmtl_concat2(const float* a, int Ha, int Wa, int Ca, int Csa, int upa, int oha, int owa,
                             const float* b, int Hb, int Wb, int Cb, int Csb, int upb, int ohb, int owb, float* y,
                             int B, int H, int W, int Cd, void* stream) {
-  if (!a || !y || B <= 0 || Ca + Cb > Cd || (upa != 1 && upa != 2)) return VMTL_ERR_ARG;
+  if (!a || !y || B <= 0 || Ca + Cb > Cd || (Cd & 3) || (Csa & 3) || (Cb && (Csb & 3)) || (upa != 1 && upa != 2))
+    return VMTL_ERR_ARG;
+  if ((long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
   if (b == nullptr && Cb != 0) return VMTL_ERR_ARG;
   if (Cb && upb != 1 && upb != 2) return VMTL_ERR_ARG;
   CatSrc s0{a, Ha, Wa, Ca, Csa, upa, oha, owa};
   CatSrc s1{b, Hb, Wb, Cb, Csb, Cb ? upb : 1, ohb, owb};
-  const long long total = (long long)B * H * W * Cd;
-  hipLaunchKernelGGL(concat2_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, s0, s1, y, B, H, W, Cd,
-                     total);
+  const long long total4 = (long long)B * H * W * (Cd >> 2);
+  hipLaunchKernelGGL(concat2_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, s0, s1, y, B, H, W, Cd,
+                     total4);
   return vmtl_check_launch();
 }
 
 extern "C" int vmtl_concat2_bwd(const float* dy, float* dx, int B, int H, int W, int Cd, int c_off, int Hs, int Ws,
                                 int C, int Cs, int up, int oh, int ow, void* stream) {
-  if (!dy || !dx || c_off < 0 || c_off + C > Cd || (up != 1 && up != 2)) return VMTL_ERR_ARG;
-  const long long total = (long long)B * Hs * Ws * Cs;
-  hipLaunchKernelGGL(concat2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, Cd,
-                     c_off, Hs, Ws, C, Cs, up, oh, ow, total);
+  if (!dy || !dx || c_off < 0 || c_off + C > Cd || (Cs & 3) || (Cd & 3) || (up != 1 && up != 2)) return VMTL_ERR_ARG;
+  if ((long long)B * Hs * Ws > 0x7fffffffLL) return VMTL_ERR_ARG;
+  const long long total4 = (long long)B * Hs * Ws * (Cs >> 2);
+  hipLaunchKernelGGL(concat2_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H, W, Cd,
+                     c_off, Hs, Ws, C, Cs, up, oh, ow, total4);
   return vmtl_check_launch();
 }
 

@@ -78,7 +78,7 @@ __device__ __forceinline__ void column_reduce_init(int M, int CQ, int Cs, float*
 }
 
 static inline int red_blocks(int M) {
-  int nb = cdiv(M, 64);
+  int nb = cdiv(M, 16);  // small maps with many channels still get a few hundred workgroups
   if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   return nb;
