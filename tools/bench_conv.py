@@ -5,7 +5,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vision_mtl_amd._lib import lib
 
 ap = argparse.ArgumentParser()

@@ -5,7 +5,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.losses import synthetic_batch
 from vision_mtl_amd.lit_module import MTLModule
 from vision_mtl_amd.utils.pipeline_utils import build_model

@@ -5,7 +5,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.cross_stitch import csnet_forward
 from oracle.losses import step_losses, synthetic_batch
 from oracle.unet_mobilenetv3 import basic_forward

@@ -6,7 +6,8 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.cross_stitch import csnet_forward
 from oracle.losses import step_losses, synthetic_batch
 from tests.util import from_dev_nhwc, to_dev_nhwc

@@ -4,7 +4,8 @@ import sys
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util import from_dev_nhwc, to_dev_nhwc
 from vision_mtl_amd import ops
 

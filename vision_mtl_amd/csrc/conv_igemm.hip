@@ -20,15 +20,18 @@
 // are 33/67/135/270/540 (+ concat 151/294/580/1072): 16-granular N tiles (48/80/144/...) keep
 // 70-95 % of the issued MFMAs useful where 32-granular tiles keep ~50 %.
 //
-// LDS tiles are [row][BK + 4] with kk contiguous: one ds_read_b128 gives a lane 4 consecutive kk
-// of its row; lane quarter q = lane>>4 takes kk 4q..4q+3 of each 16-wide k-group and element e
-// feeds MFMA e (k quadruple {e, 4+e, 8+e, 12+e}) - identical mapping for A and B.
+// LDS tiles are [row][BK] with kk contiguous: one ds_read_b128 gives a lane 4 consecutive kk of its
+// row; lane quarter q = lane>>4 takes kk 4q..4q+3 of each 16-wide k-group and element e feeds MFMA e
+// (k quadruple {e, 4+e, 8+e, 12+e}) - identical mapping for A and B.  Rows are 128 bytes (8 slots of
+// 16 bytes) and slot s of row r lives at slot s ^ (r & 7): with that swizzle every 16-lane group of the
+// fragment ds_read_b128 (and every 8-lane group of the staging ds_write_b128) touches 16 (8) distinct
+// slots - conflict-free, where the padded [row][BK+4] layout measured 36 % conflict cycles.
 #include <stdlib.h>
 
 #include "common.h"
 
 #define BK 32
-#define LDT (BK + 4)
+#define LDT BK  // un-padded 128-byte rows; the 16-byte slot index is XOR-swizzled with (row & 7)
 
 struct ConvP {
   const float* x;     // [B][H][W][Cs]
@@ -133,12 +136,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   auto store_tile = [&](int buf) {
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BN * LDT;
+    const int ks = (k4 ^ (r0 & 7)) * 4;  // (r0 + 32 i) & 7 == r0 & 7
 #pragma unroll
     for (int i = 0; i < RA; ++i)
-      if (BM % 32 == 0 || r0 + 32 * i < BM) *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDT + k4 * 4) = ra[i];
+      if (BM % 32 == 0 || r0 + 32 * i < BM) *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * LDT + ks) = ra[i];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      if (BN % 32 == 0 || r0 + 32 * i < BN) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDT + k4 * 4) = rb[i];
+      if (BN % 32 == 0 || r0 + 32 * i < BN) *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * LDT + ks) = rb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -156,15 +160,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) load_tile();  // global loads stay in flight under the MFMAs
-    const float* a = As + cur * BM * LDT + (wm * TM * 16 + l15) * LDT + lq * 4;
-    const float* b = Bs + cur * BN * LDT + (wn * TN * 16 + l15) * LDT + lq * 4;
+    // fragment rows are (tile base + l15) with tile bases multiples of 16: row & 7 == l15 & 7
+    const float* a = As + cur * BM * LDT + (wm * TM * 16 + l15) * LDT;
+    const float* b = Bs + cur * BN * LDT + (wn * TN * 16 + l15) * LDT;
 #pragma unroll
     for (int kg = 0; kg < BK / 16; ++kg) {
+      const int so = ((kg * 4 + lq) ^ (l15 & 7)) * 4;
       f32x4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * LDT + kg * 16);
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * LDT + so);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 16 * LDT + kg * 16);
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 16 * LDT + so);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -295,6 +301,7 @@ struct WgradP {
   int KH, KW, stride, pad;
   int Ktot, M;
   int chunk;        // pixels per z-slice (multiple of BP)
+  int tiles_kk, tiles_co, splits;
 };
 
 #define BP 32
@@ -320,9 +327,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int lane = tid & 63, wn = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  const int kk0 = blockIdx.x * WG_BNK;
-  const int co0 = blockIdx.y * BMC;
-  const int p_begin = blockIdx.z * p.chunk;
+  // 1-D grid, XCD-aware: workgroups with consecutive remapped ids share an XCD (one L2); the kk/co
+  // tiles of ONE pixel slice are consecutive, so the slice's x / dy rows are fetched from HBM once per
+  // XCD instead of once per tile (measured before: 97 % L2 misses, 2.6 GB fabric traffic on blk4).
+  const int tiles = p.tiles_kk * p.tiles_co;
+  const int bid = xcd_remap(blockIdx.x, tiles * p.splits);
+  const int zsl = bid / tiles, trem = bid - zsl * tiles;
+  const int kk0 = (trem % p.tiles_kk) * WG_BNK;
+  const int co0 = (trem / p.tiles_kk) * BMC;
+  const int p_begin = zsl * p.chunk;
   const int p_end = min(p.M, p_begin + p.chunk);
 
   // X loader: fixed (tap, ci) column per thread, rows advance with the chunk
@@ -334,6 +347,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int dh = tap / p.KW - p.pad;
   const int dw = tap % p.KW - p.pad;
   const int hw = p.Ho * p.Wo;
+
+  // per-row pixel coordinates of this thread's XP gather rows, advanced by BP pixels per chunk with
+  // adds / compares only (two integer divisions per row and chunk made this kernel VALU-issue bound:
+  // 7 VALU instructions per MFMA on the narrow tiles)
+  int xb[XP], xho[XP], xwo[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int m = p_begin + xr + XROWS * i;
+    const int b = m / hw;
+    const int rem = m - b * hw;
+    xb[i] = b;
+    xho[i] = rem / p.Wo;
+    xwo[i] = rem - xho[i] * p.Wo;
+  }
 
   f32x4 ry[YIT], rx[XP];
   auto load_tile = [&](int pp) {
@@ -351,15 +378,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       const int m = pp + xr + XROWS * i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (xok && m < p_end) {
-        const int b = m / hw;
-        const int rem = m - b * hw;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
-        const int h = ho * p.stride + dh, w = wo * p.stride + dw;
+        const int h = xho[i] * p.stride + dh, w = xwo[i] * p.stride + dw;
         if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(b * p.H + h) * p.W + w) * p.Cs + ci);
+          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(xb[i] * p.H + h) * p.W + w) * p.Cs + ci);
       }
       rx[i] = v;
+      // advance this row by BP pixels
+      xwo[i] += BP;
+      while (xwo[i] >= p.Wo) {
+        xwo[i] -= p.Wo;
+        if (++xho[i] == p.Ho) {
+          xho[i] = 0;
+          ++xb[i];
+        }
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     cur ^= 1;
   }
 
-  float* slab = p.slabs + (size_t)blockIdx.z * p.Nw * p.Ktot;
+  float* slab = p.slabs + (size_t)zsl * p.Nw * p.Ktot;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -571,8 +603,10 @@ static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM>), dim3(cdiv(p.Ktot, WG_BNK), cdiv(p.Nw, BMC), splits), dim3(256), lds,
-                     st, p);
+  p.tiles_kk = cdiv(p.Ktot, WG_BNK);
+  p.tiles_co = cdiv(p.Nw, BMC);
+  p.splits = splits;
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
 

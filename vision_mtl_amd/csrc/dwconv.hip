@@ -67,22 +67,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
 }
 
 // weight gradient: dw[c][tap] = sum over output pixels of dy * x(shifted).  Grid = (channel panels of
-// 16 float4 quads, row blocks); a workgroup's 256 threads are 16 quads x 16 row lanes, each thread keeps
-// its K*K tap sums in registers over its rows, row lanes are folded with wave shuffles + one LDS pass,
-// and every workgroup writes one partial row [row block][tap][Cs]; the finalize sums row blocks in fp64.
-#define DWW_QUADS 16
-#define DWW_MAX_RB 64
+// QL float4 quads, row blocks); a workgroup's 256 threads are QL quad lanes x (256/QL) row lanes with
+// QL = min(16, pow2 >= quads) so narrow maps (C = 16..72) still use every lane.  Each thread keeps its
+// K*K tap sums in registers over its rows; row lanes are folded with wave shuffles + one LDS pass and
+// every workgroup writes one partial row [row block][tap][Cs]; the finalize sums row blocks in fp64.
+#define DWW_MAX_RB 256
 
 template <int KK>
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ dy, int H, int W, int Cs,
-                                                           int Ho, int Wo, int K, int stride, int pad, int M,
+                                                           int Ho, int Wo, int K, int stride, int pad, int M, int QL,
                                                            float* partial) {
-  __shared__ f32x4 red[4][DWW_QUADS];
+  __shared__ f32x4 red[4][16];
   const int CQ = Cs >> 2;
-  const int ql = threadIdx.x & 15;        // quad within the panel (lanes 0-15 of each 16-lane group)
-  const int rl = threadIdx.x >> 4;        // row lane 0..15 (4 per wave x 4 waves)
-  const int q = blockIdx.x * DWW_QUADS + ql;
+  const int ql = threadIdx.x & (QL - 1);  // quad lane
+  const int rl = threadIdx.x / QL;        // row lane 0 .. 256/QL-1
+  const int RL = 256 / QL;
+  const int q = blockIdx.x * QL + ql;
   const int nrb = gridDim.y;
   const int rows_per_blk = (M + nrb - 1) / nrb;
   const int r_begin = blockIdx.y * rows_per_blk;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (q < CQ)
-    for (int r = r_begin + rl; r < r_end; r += 16) {
+    for (int r = r_begin + rl; r < r_end; r += RL) {
       const int wo = r % Wo, ho = (r / Wo) % Ho, b = r / (Wo * Ho);
       const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (size_t)r * Cs + (size_t)q * 4);
 #pragma unroll
@@ -106,15 +107,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < KK; ++t) {
     f32x4 v = acc[t];
+    for (int o = QL; o < 64; o <<= 1) {  // fold the row lanes of this wave (lane bits >= log2(QL))
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {  // fold the 4 row lanes of this wave (lane bits 4,5)
-      v[e] += __shfl_xor(v[e], 16, 64);
-      v[e] += __shfl_xor(v[e], 32, 64);
+      for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
     }
     __syncthreads();
-    if ((threadIdx.x & 63) < 16) red[wave][ql] = v;
+    if ((int)(threadIdx.x & 63) < QL) red[wave][ql] = v;
     __syncthreads();
-    if (threadIdx.x < 16 && q < CQ) {
+    if ((int)threadIdx.x < QL && q < CQ) {
       const f32x4 s = ((red[0][ql] + red[1][ql]) + red[2][ql]) + red[3][ql];
       *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * KK + t) * Cs + (size_t)q * 4) = s;
     }
@@ -166,24 +166,28 @@ extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx,
   return vmtl_check_launch();
 }
 
-// partial: at least 64 * K*K * Cs floats (vmtl_reduce_rows(M) * K*K * Cs always suffices).  dw: torch (C,1,K,K) layout.
+// partial: at least 256 * K*K * Cs floats (vmtl_reduce_rows(M) * K*K * Cs always suffices).  dw: torch (C,1,K,K) layout.
 extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,
                                       int C, int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream) {
   if (!x || !dy || !partial || !dw || C <= 0 || C > Cs) return VMTL_ERR_ARG;
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   hipStream_t st = (hipStream_t)stream;
   const int M = B * Ho * Wo;
-  const int panels = cdiv(Cs >> 2, DWW_QUADS);
-  int nblk = cdiv(1024, panels);               // ~1024 workgroups in total
-  if (nblk > cdiv(M, 64)) nblk = cdiv(M, 64);  // >= 64 rows (4 per row lane) per workgroup
+  const int CQ = Cs >> 2;
+  int QL = 16;
+  while (QL > 1 && (QL >> 1) >= CQ) QL >>= 1;  // smallest power of two >= CQ, at most 16
+  const int panels = cdiv(CQ, QL);
+  const int rows_per_pass = 256 / QL;
+  int nblk = cdiv(1024, panels);                                           // ~1024 workgroups in total
+  if (nblk > cdiv(M, 4 * rows_per_pass)) nblk = cdiv(M, 4 * rows_per_pass);  // >= 4 rows per row lane
   if (nblk > DWW_MAX_RB) nblk = DWW_MAX_RB;
   if (nblk < 1) nblk = 1;
   if (K == 3)
     hipLaunchKernelGGL((dwconv_bwd_w_kernel<9>), dim3(panels, nblk), dim3(256), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
-                       stride, pad, M, partial);
+                       stride, pad, M, QL, partial);
   else
     hipLaunchKernelGGL((dwconv_bwd_w_kernel<25>), dim3(panels, nblk), dim3(256), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
-                       stride, pad, M, partial);
+                       stride, pad, M, QL, partial);
   hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(C * K * K), dim3(256), 0, st, partial, nblk, K * K, C, Cs,
                      dw);
   return vmtl_check_launch();

@@ -126,6 +126,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None)
         ctx.slots = (_slot(weight), _slot(bias))
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" tensor for the stats output
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -135,6 +136,8 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, dy, _dstats):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
+        if dy is None:
+            return None, None, None, None, None, None
         dy = _req(dy, "dy")
         B, H, W, Cs = x.shape
         Cout, Cin, KH, KW = weight.shape
@@ -248,7 +251,7 @@ class _DwConv(torch.autograd.Function):
             _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=dx, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride,
                pad=pad)
         if ctx.needs_input_grad[1]:
-            partial = _empty((64, K * K, Cs), x)
+            partial = _empty((256, K * K, Cs), x)
             dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
             _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo,
                K=K, stride=stride, pad=pad)
