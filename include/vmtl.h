@@ -65,6 +65,10 @@ int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, floa
 /* torch parameter layout <-> packed GEMM operand (formula in csrc/pack.hip). */
 int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
                       long long sr0, long long st, long long sc, int flip, void* stream);
+/* batched form: descs = device array of n records {src*, dst*, i64 sr1, sr0, st, sc, start; i32 R1, R0, T, C,
+ * Cs, flip} (vmtl_pack_desc_bytes() bytes each), start = first flat work index; total = sum R1*R0*T*Cs. */
+int vmtl_pack_desc_bytes(void);
+int vmtl_pack_weights_batch(const void* descs, int n, long long total, void* stream);
 int vmtl_pack_weights_slice(const float* src, float* dst, int R0, int T, int C, int group, long long sr0,
                             long long st, long long sc, int flip, void* stream);
 int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,

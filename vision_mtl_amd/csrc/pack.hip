@@ -31,6 +31,52 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
   }
 }
 
+// ---- batched form: one launch packs MANY weight tensors (every conv of the model, forward and
+// data-gradient layouts) from a descriptor table in device memory.  A step then pays one launch
+// instead of ~135 five-microsecond ones.
+struct PackDesc {
+  const float* src;
+  float* dst;
+  long long sr1, sr0, st, sc;
+  long long start;  // first flat work index of this descriptor
+  int R1, R0, T, C, Cs, flip;
+};
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int n, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;  // last descriptor with start <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].start <= i) lo = mid;
+      else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    const long long j = i - d.start;
+    const int c = (int)(j % d.Cs);
+    long long rest = j / d.Cs;
+    const int tp = (int)(rest % d.T);
+    rest /= d.T;
+    const int r0 = (int)(rest % d.R0);
+    const int r1 = (int)(rest / d.R0);
+    const int t = d.flip ? d.T - 1 - tp : tp;
+    d.dst[j] = c < d.C ? d.src[r1 * d.sr1 + r0 * d.sr0 + t * d.st + c * d.sc] : 0.f;
+  }
+}
+
+extern "C" int vmtl_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
+
+// descs: device array of n descriptors laid out as struct PackDesc (see vmtl_pack_desc_bytes);
+// total = sum of R1*R0*T*Cs over the table.
+extern "C" int vmtl_pack_weights_batch(const void* descs, int n, long long total, void* stream) {
+  if (!descs || n <= 0 || total <= 0) return VMTL_ERR_ARG;
+  long long nb = cdivll(total, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream,
+                     (const PackDesc*)descs, n, total);
+  return vmtl_check_launch();
+}
+
 // writes only channels [0, C) of every `group`-wide tap group (dst may point at a channel offset):
 // lets two weight tensors share one packed operand (fused heads).
 __global__ __launch_bounds__(256) void pack_slice_kernel(const float* __restrict__ src, float* __restrict__ dst, int R0,

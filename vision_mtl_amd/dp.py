@@ -62,6 +62,7 @@ class FlatArena:
         st["step"] += 1
         ops.adam_step(self.flat_param, self.flat_grad, st["m"], st["v"], st["step"], lr, betas, eps, weight_decay,
                       grad_scale)
+        ops.packs.invalidate()  # parameters changed through raw pointers: packed operands are stale
 
 
 def init_distributed():

@@ -27,6 +27,7 @@ class BasicMTLModel(nn.Module):
         self.depth_head = SegmentationHead(last, 1, activation=activation, kernel_size=3)
 
     def forward(self, x: torch.Tensor) -> t.Dict[str, torch.Tensor]:
+        ops.packs.refresh()  # one batched weight-packing launch for the whole step
         dec = self.backbone.run(L.from_nchw(x))
         sh, dh = self.segm_head[0], self.depth_head[0]
         # both 3x3 heads read the same decoder map: one implicit GEMM with N = C + 1 output channels

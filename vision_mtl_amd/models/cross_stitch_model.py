@@ -158,6 +158,7 @@ class CSNet(nn.Module):
     def forward(self, x: torch.Tensor) -> dict:
         if self._program is None:
             self._compile()
+        ops.packs.refresh()  # one batched weight-packing launch for the whole step
         x0 = L.from_nchw(x)
         feats = {task: x0 for task in self.model_names}
         skips = {task: [] for task in self.model_names}

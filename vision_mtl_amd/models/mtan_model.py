@@ -142,6 +142,7 @@ class MTANMiniUnet(nn.Module):
             task: nn.Conv2d(dec_out[-1], n_out, kernel_size=1) for task, n_out in map_tasks_to_num_channels.items()})
 
     def forward(self, x: torch.Tensor) -> t.Dict[str, torch.Tensor]:
+        L.ops.packs.refresh()  # one batched weight-packing launch for the whole step
         enc = L.from_nchw(x)
         feats, attn = [], None
         for layer in self.enc_layers:

@@ -64,6 +64,72 @@ def _reduce_rows(M: int) -> int:
 
 
 # ----------------------------------------------------------------------------- packing
+class _PackCache:
+    """Packed GEMM operands of the model's weights, refreshed by ONE batched launch per step.
+
+    get() hands out a persistent packed buffer for (weight, layout).  An entry is valid while the weight's
+    storage, autograd version and the global epoch are unchanged (torch optimizers bump the version;
+    FlatArena.adam_step() and refresh() bump the epoch).  refresh() re-packs every known entry with a
+    single vmtl_pack_weights_batch launch; a miss falls back to an individual pack and marks the
+    descriptor table for a rebuild (done outside graph capture, during warm-up)."""
+
+    def __init__(self):
+        self.entries = {}  # key -> dict(dst, params, weight_ref, ptr, version, epoch)
+        self.epoch = 0
+        self.table = None  # (device uint8 tensor, n, total)
+        self.dirty = True
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def get(self, weight, kind, params):
+        key = (id(weight), kind, params)
+        e = self.entries.get(key)
+        if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
+            return e["dst"]
+        R1, R0, T, C, Cs = params[:5]
+        if e is None or e["ptr"] != weight.data_ptr():
+            e = {"dst": _empty((R1 * R0, T * Cs), weight), "params": params, "weight": weight, "ptr": weight.data_ptr()}
+            self.entries[key] = e
+            self.dirty = True
+        pack(weight, *params, out=e["dst"])
+        e["version"], e["epoch"] = weight._version, self.epoch
+        return e["dst"]
+
+    def _build_table(self):
+        import struct
+
+        live = [e for e in self.entries.values() if e["weight"].data_ptr() == e["ptr"]]
+        recs, start = [], 0
+        for e in live:
+            R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
+            recs.append(struct.pack("<QQqqqqqiiiiii", e["ptr"], e["dst"].data_ptr(), sr1, sr0, st, sc, start, R1, R0, T,
+                                    C, Cs, flip))
+            start += R1 * R0 * T * Cs
+        size = lib().raw("vmtl_pack_desc_bytes")()
+        blob = b"".join(r.ljust(size, b"\0") for r in recs)
+        dev = live[0]["dst"].device
+        table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        self.table, self.live, self.dirty = (table, len(recs), start), live, False
+
+    def refresh(self):
+        """Re-pack every known weight (call once at the start of a step, before the forward)."""
+        if not self.entries:
+            return
+        self.epoch += 1
+        if self.dirty:
+            if torch.cuda.is_current_stream_capturing():
+                return  # keep per-call packing inside this capture; the table is rebuilt on the next eager step
+            self._build_table()
+        table, n, total = self.table
+        _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
+        for e in self.live:
+            e["version"], e["epoch"] = e["weight"]._version, self.epoch
+
+
+packs = _PackCache()
+
+
 def pack(src, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None):
     dst = _empty((R1 * R0, T * Cs), src) if out is None else out
     _k("vmtl_pack_weights", src=src, dst=dst, R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st, sc=sc, flip=flip)
@@ -116,7 +182,7 @@ class _Conv2d(torch.autograd.Function):
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
         ldy = ceil4(Cout)
-        wp = pack(weight, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK)
+        wp = packs.get(weight, "fwd", (1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, 0))
         y = _empty((B, Ho, Wo, ldy), x)
         stats = None
         if want_stats:
@@ -147,7 +213,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if stride != 1:
                 raise NotImplementedError("data gradient of a strided dense conv is not on the hot path")
-            wd = pack(weight, 1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, flip=1)
+            wd = packs.get(weight, "dgrad", (1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, 1))
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=Cout)
         if ctx.needs_input_grad[1]:
@@ -181,7 +247,7 @@ class _ConvT2x2(torch.autograd.Function):
         if tuple(weight.shape[2:]) != (2, 2) or ceil4(Cin) != Cs:
             raise ValueError("conv_transpose2x2: weight must be (Cin, Cout, 2, 2) matching the input channels")
         ldy = ceil4(Cout)
-        wp = pack(weight, 4, Cout, 1, Cin, Cs, 1, 4, 0, Cout * 4)
+        wp = packs.get(weight, "ct_fwd", (4, Cout, 1, Cin, Cs, 1, 4, 0, Cout * 4, 0))
         y = _empty((B, 2 * H, 2 * W, ldy), x)
         _conv_launch(x, wp, bias, y, None, B, H, W, Cs, H, W, ldy, 4 * Cout, Cout, 1, 1, 1, 0, shuffle=1, cin=Cin)
         ctx.save_for_backward(x, weight)
@@ -198,7 +264,7 @@ class _ConvT2x2(torch.autograd.Function):
         ldy = dy.shape[3]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:  # a 2x2 / stride-2 conv over dy
-            wd = pack(weight, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4)
+            wd = packs.get(weight, "ct_bwd", (1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, 0))
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, Cin, 2, 2, 2, 0, cin=Cout)
         if ctx.needs_input_grad[1]:  # weight gradient of that same conv, with x in the role of its output gradient
@@ -229,7 +295,7 @@ class _DwConv(torch.autograd.Function):
             raise ValueError("dwconv: weight must be (C, 1, K, K) matching the input channels")
         Ho = (H + 2 * pad - K) // stride + 1
         Wo = (W + 2 * pad - K) // stride + 1
-        wp = pack(weight, 1, 1, K * K, C, Cs, 0, 0, 1, K * K)
+        wp = packs.get(weight, "dw", (1, 1, K * K, C, Cs, 0, 0, 1, K * K, 0))
         y = _empty((B, Ho, Wo, Cs), x)
         _k("vmtl_dwconv_fwd", x=x, wp=wp, y=y, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
         ctx.save_for_backward(x, weight, wp)
