@@ -74,19 +74,20 @@ def time_conv_kernels(module, batch, reps=3):
     stream = torch.cuda.current_stream().cuda_stream
     fam = {"vmtl_conv2d_fwd": dict(flop=0.0, ms=0.0, launches=0), "vmtl_conv2d_wgrad": dict(flop=0.0, ms=0.0, launches=0)}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for name, kw, flop in rec:  # flop = algorithmic FLOPs of the launch (logical channels, no padding lanes)
+    for name, kw, flop, xflop in rec:  # flop = algorithmic (reference-formulation) FLOPs, xflop = executed
         lib().callk(name, stream=stream, **kw)  # warm
         e0.record()
         for _ in range(reps):
             lib().callk(name, stream=stream, **kw)
         e1.record()
         e1.synchronize()
-        f = fam[name]
+        f = fam["vmtl_conv2d_wgrad" if name == "vmtl_conv2d_wgrad" else "vmtl_conv2d_fwd"]
         ms = e0.elapsed_time(e1) / reps
         f["flop"] += flop
+        f["xflop"] = f.get("xflop", 0.0) + xflop
         f["ms"] += ms
         f["launches"] += 1
-        if os.environ.get("VMTL_CONV_TABLE"):
+        if os.environ.get("VMTL_CONV_TABLE") and "Ho" in kw:
             M = kw["B"] * kw["Ho"] * kw["Wo"]
             log(f"{name[12:]:6s} M={M:8d} N={kw['Nw']:5d} K={kw['KH'] * kw['KW'] * kw['Cs']:6d} "
                 f"k{kw['KH']}s{kw['stride']} {ms * 1e3:9.1f} us {flop / ms / 1e9:7.1f} TF")
@@ -263,6 +264,7 @@ def main():
                                "launches_per_step": ig["launches"],
                                "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
                                "flop_per_launch": round(ig["flop"] / max(ig["launches"], 1)),
+                               "executed_tflops": round(ig.get("xflop", ig["flop"]) / (ig["ms"] * 1e-3) / 1e12, 2),
                                "ms_per_step_in_kernel": round(ig["ms"], 3)}
             wg = fam["vmtl_conv2d_wgrad"]
             if wg["ms"] > 0:

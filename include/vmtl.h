@@ -46,6 +46,17 @@ int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
 int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
 
+/* nearest-x2 upsample of xl + concat with skip + 3x3/pad-1 conv (smp DecoderBlock entry, reference
+ * utils/model_utils.py:25-34) as four 2x2 phase convolutions on the low-res map: wp_eff from
+ * vmtl_pack_up2_fwd ([4][Cout][4*C0s + 9*C1s]); y is [B][2*H2][2*W2][ldy].  Backward uses
+ * vmtl_conv2d_fwd(k4,s2,p1) over dY with vmtl_pack_up2_dgrad, vmtl_conv2d_wgrad(k4,s2,p1) + vmtl_unpack_up2. */
+int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const float* wp_eff, float* y, float* stats,
+                        int B, int H2, int W2, int C0s, int C1s, int ldy, int Cout, void* stream);
+int vmtl_conv2d_up2_stats_block(int B, int H2, int W2, int ldy);
+int vmtl_pack_up2_fwd(const float* w, float* dst, int Cout, int C0, int C0s, int C1, int C1s, void* stream);
+int vmtl_pack_up2_dgrad(const float* w, float* dst, int Cout, int Cos, int C0, int Cin, void* stream);
+int vmtl_unpack_up2(const float* slabs, float* grad, int Cout, int Cos, int C0, int Cin, int nslabs, void* stream);
+
 /* slabs[z][n][kk] = sum_{m in pixel slice z} dy[m][n] * gather(x)[m][kk]  (packed layout, plain
  * stores, no atomics).  splits = vmtl_conv2d_wgrad_splits(B*Ho*Wo, Nw, KH*KW*Cs); the caller
  * provides splits*Nw*KH*KW*Cs floats and vmtl_unpack_weights(..., nslabs=splits) adds the slabs

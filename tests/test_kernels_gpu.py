@@ -129,6 +129,49 @@ def test_dwconv(dev, case):
     assert_close(wd.grad.cpu(), wr.grad, what="dwconv wgrad")
 
 
+@pytest.mark.parametrize("case", [(2, 135, 16, 4, 6, 67), (1, 960, 112, 3, 5, 540), (2, 67, 0, 8, 8, 33),
+                                  (3, 270, 24, 5, 3, 135), (2, 20, 7, 1, 1, 9)])
+def test_up2_conv(dev, case):
+    """Phase-decomposed decoder-block entry == conv3x3(cat[nearest_x2(x), skip]) (values, fused BatchNorm
+    partials, and the gradients of x, skip and the weight)."""
+    ops = _ops()
+    B, C0, C1, H2, W2, Cout = case
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(B, C0, H2, W2, generator=g)
+    sk = torch.randn(B, C1, 2 * H2, 2 * W2, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / ((C0 + C1) * 9) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    skr = sk.clone().requires_grad_(True) if C1 else None
+    up = F.interpolate(xr, scale_factor=2, mode="nearest")
+    yr = F.conv2d(torch.cat([up, skr], 1) if C1 else up, wr, None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    skd = to_dev_nhwc(sk, dev).requires_grad_(True) if C1 else None
+    wd = w.to(dev).requires_grad_(True)
+    y, stats = ops.up2_conv(xd, C0, skd, wd, want_stats=True)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="up2 fwd")
+    if y.shape[-1] > Cout:
+        assert y[..., Cout:].abs().max().item() == 0.0
+    if stats is not None:
+        from vision_mtl_amd._lib import lib
+
+        Mq = B * H2 * W2
+        rpb = lib().raw("vmtl_conv2d_up2_stats_block")(B, H2, W2, y.shape[-1])
+        assert Mq % rpb == 0 and stats.shape[0] == 4 * (Mq // rpb)
+        st = stats.double().cpu()
+        mean = st[:, 0].mean(0)  # equal-sized blocks
+        var = (st[:, 1] + rpb * (st[:, 0] - mean) ** 2).sum(0) / (4 * Mq)
+        yo = yr.detach().double()
+        assert_close(mean[:Cout], yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="up2 stats mean")
+        assert_close(var[:Cout], yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="up2 stats var")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C0), xr.grad, what="up2 dx")
+    assert_close(wd.grad.cpu(), wr.grad, what="up2 dw")
+    if C1:
+        assert_close(from_dev_nhwc(skd.grad, C1), skr.grad, what="up2 dskip")
+
+
 def test_dual_head(dev):
     """Fused segm+depth heads == two separate F.conv2d heads (values and all gradients)."""
     ops = _ops()

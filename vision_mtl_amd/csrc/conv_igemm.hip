@@ -48,9 +48,14 @@ struct ConvP {
   int act;
   int shuffle;        // 1: rows n=(u*2+v)*Cout+co are scattered to (2h+u, 2w+v, co)
   int tiles_m, tiles_n;
+  // UP2 mode (nearest-x2 upsample of x, concat with x2, 3x3 conv, evaluated as four 2x2 phase convs on
+  // the low-res map): x is the LOW-res source [B][H][W][Cs]; x2 the full-res skip [B][2H][2W][C2s] (may
+  // be null); wp holds 4 phase matrices [4][Nw][Ktot], Ktot = 4*Cs + 9*C2s; M = B*H*W rows per phase.
+  const float* x2;
+  int C2s;
 };
 
-template <int TM, int TN, int WAVES_M, int WAVES_N>
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = WAVES_M * TM * 16;
   constexpr int BN = WAVES_N * TN * 16;
@@ -71,7 +76,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = xcd_remap(blockIdx.x, nwg);
   const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int n0 = tile_n * BN;
+  // UP2: the row tiles are grouped by output phase (a, b) = (row parity, column parity)
+  const int tiles_q = UP2 ? p.tiles_m >> 2 : p.tiles_m;
+  const int phase = UP2 ? tile_m / tiles_q : 0;
+  const int pa = phase >> 1, pb = phase & 1;
+  const int m0 = (UP2 ? tile_m - phase * tiles_q : tile_m) * BM;
+  const float* wp = p.wp + (UP2 ? (size_t)phase * p.Nw * p.Ktot : 0);
 
   // ---- per-thread loader geometry ----
   const int k4 = tid & 7;   // float4 column inside the BK chunk
@@ -87,20 +98,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
       pixbase[i] = b * p.H * p.W;
-      hb[i] = ho * p.stride - p.pad;
-      wb[i] = wo * p.stride - p.pad;
+      hb[i] = UP2 ? ho - 1 + pa : ho * p.stride - p.pad;  // UP2: (Ho, Wo) are the low-res dims here
+      wb[i] = UP2 ? wo - 1 + pb : wo * p.stride - p.pad;
     } else {
       pixbase[i] = 0;
       hb[i] = -(1 << 20);  // forces the bounds test to fail
       wb[i] = 0;
     }
   }
-  // running (tap, ci) of this thread's float4 column
+  // running (segment, tap, ci) of this thread's float4 column.  Segment 0 gathers from x with a
+  // KHxKW tap grid (UP2: 2x2 on the low-res map); segment 1 (UP2 only) gathers 3x3 taps from x2.
   int kk = k4 * 4;
-  int tap = kk / p.Cs;
-  int ci = kk - tap * p.Cs;
-  int dh = tap / p.KW;
-  int dw = tap - dh * p.KW;
+  int seg = 0, dh = 0, dw = 0, ci = kk;
+  int cseg = p.Cs, kwseg = UP2 ? 2 : p.KW;
+  auto normalize = [&]() {
+    while (ci >= cseg) {
+      ci -= cseg;
+      if (++dw == kwseg) {
+        dw = 0;
+        ++dh;
+        if (UP2 && seg == 0 && dh == 2) {
+          if (p.C2s == 0) { dh = 1 << 20; break; }  // no skip: the K range ends here (kk >= Ktot anyway)
+          seg = 1; dh = 0; cseg = p.C2s; kwseg = 3;
+        }
+      }
+    }
+  };
+  normalize();
 
   f32x4 ra[RA], rb[RB];
 
@@ -108,12 +132,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const bool kok = kk < p.Ktot;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int h = hb[i] + dh, w = wb[i] + dw;
-      const bool ok = kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t off = (size_t)(pixbase[i] + h * p.W + w) * p.Cs + ci;
-        v = *reinterpret_cast<const f32x4*>(p.x + off);
+      if (!UP2 || seg == 0) {
+        const int h = hb[i] + dh, w = wb[i] + dw;
+        if (kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+          v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(pixbase[i] + h * p.W + w) * p.Cs + ci);
+      } else {
+        // full-res skip: output pixel (2*h2 + pa, 2*w2 + pb), tap offset dh-1 / dw-1; hb = h2 - 1 + pa
+        const int h = 2 * hb[i] + 1 - pa + dh, w = 2 * wb[i] + 1 - pb + dw;
+        if (kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W))
+          v = *reinterpret_cast<const f32x4*>(p.x2 + ((size_t)4 * pixbase[i] + (size_t)h * (2 * p.W) + w) * p.C2s + ci);
       }
       ra[i] = v;
     }
@@ -121,17 +149,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < RB; ++i) {
       const int n = n0 + r0 + 32 * i;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kok && n < p.Nw && r0 + 32 * i < BN) v = *reinterpret_cast<const f32x4*>(p.wp + (size_t)n * p.Ktot + kk);
+      if (kok && n < p.Nw && r0 + 32 * i < BN) v = *reinterpret_cast<const f32x4*>(wp + (size_t)n * p.Ktot + kk);
       rb[i] = v;
     }
     // advance to the next BK chunk
     kk += BK;
     ci += BK;
-    while (ci >= p.Cs) {
-      ci -= p.Cs;
-      ++dw;
-      if (dw == p.KW) { dw = 0; ++dh; }
-    }
+    normalize();
   };
   auto store_tile = [&](int buf) {
     float* a = As + buf * BM * LDT;
@@ -199,7 +223,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         const int m = m0 + (wm * TM + i) * 16 + 4 * lq + r;
         if (m >= p.M) continue;
         float v = act_fwd(acc[i][j][r] + bv[j], p.act);
-        if (!p.shuffle) {
+        if (UP2) {
+          if (n < p.ldy) {
+            if (n >= p.Cout) v = 0.f;
+            const int b_ = m / hw, rem = m - b_ * hw;
+            const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
+            p.y[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
+          }
+        } else if (!p.shuffle) {
           if (n < p.ldy) {
             if (n >= p.Cout) v = 0.f;
             p.y[(size_t)m * p.ldy + n] = v;
@@ -504,19 +535,19 @@ extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
   return kTiles[conv_pick_tile(B * Ho * Wo, ldy)].bm;
 }
 
-template <int TM, int TN, int WMV, int WNV>
+template <int TM, int TN, int WMV, int WNV, bool UP2 = false>
 static int launch_conv(ConvP& p, hipStream_t st) {
   constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16;
-  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_m = cdiv(p.M, BM) * (UP2 ? 4 : 1);
   p.tiles_n = cdiv(p.shuffle ? p.Nw : p.ldy, BN);
   const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
 
@@ -535,7 +566,7 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats;
   p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
-  p.act = act; p.shuffle = shuffle;
+  p.act = act; p.shuffle = shuffle; p.x2 = nullptr; p.C2s = 0;
   hipStream_t st = (hipStream_t)stream;
   if (shuffle && ldy > Cout &&  // the scatter only writes co < Cout: keep the pad-channel invariant
       hipMemsetAsync(y, 0, (size_t)B * 4 * Ho * Wo * ldy * sizeof(float), st) != hipSuccess)
@@ -553,6 +584,57 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
     case 9: return launch_conv<1, 4, 4, 1>(p, st);
     case 10: return launch_conv<2, 4, 2, 2>(p, st);
     default: return launch_conv<1, 9, 4, 1>(p, st);
+  }
+}
+
+// ---- nearest-x2 upsample + concat + 3x3 conv as four 2x2 phase convolutions ------------------------
+// y[b, 2h+a, 2w+c, n] = sum_{ty,tx,ci} Weff[a][c][n][ty][tx][ci] * xl[b, h-1+a+ty, w-1+c+tx, ci]
+//                     + sum_{dh,dw,cj} W[n][C0+cj][dh][dw] * skip[b, 2h+a+dh-1, 2w+c+dw-1, cj]
+// (Weff = the 3x3 taps that fall on the same low-res pixel, pre-summed: vmtl_pack_up2_fwd).  Identical
+// to conv3x3(cat[nearest2(xl), skip]) up to fp32 summation order, with 4 instead of 9 taps on the
+// upsampled channels and no materialised upsample / concat tensor.
+static int up2_pick_tile(int Mq, int ncols) {
+  if (const char* f = getenv("VMTL_FORCE_TILE")) {
+    const int id = atoi(f);
+    if (id >= 0 && id < 12) return id;
+  }
+  const int big = pick_in(0, 8, ncols);
+  if ((long long)cdiv(Mq, 128) * 4 * cdiv(ncols, kTiles[big].bn) < 384) return pick_in(8, 12, ncols);
+  return big;
+}
+
+extern "C" int vmtl_conv2d_up2_stats_block(int B, int H2, int W2, int ldy) {
+  return kTiles[up2_pick_tile(B * H2 * W2, ldy)].bm;
+}
+
+// stats (optional): [4 * ceil(B*H2*W2 / block)][2][ldy]; only valid when block divides B*H2*W2
+extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const float* wp_eff, float* y, float* stats,
+                                   int B, int H2, int W2, int C0s, int C1s, int ldy, int Cout, void* stream) {
+  if (!xl || !wp_eff || !y || B <= 0 || H2 <= 0 || W2 <= 0 || C0s <= 0 || (C0s & 3) || (C1s & 3) || C1s < 0)
+    return VMTL_ERR_ARG;
+  if ((skip == nullptr) != (C1s == 0) || Cout <= 0 || Cout > ldy) return VMTL_ERR_ARG;
+  if ((long long)B * H2 * W2 * 4 > 0x7fffffffLL) return VMTL_ERR_ARG;
+  ConvP p;
+  p.x = xl; p.x2 = skip; p.wp = wp_eff; p.bias = nullptr; p.y = y; p.stats = stats;
+  p.B = B; p.H = H2; p.W = W2; p.Cs = C0s; p.C2s = C1s; p.Ho = H2; p.Wo = W2; p.ldy = ldy; p.Nw = Cout;
+  p.Cout = Cout; p.KH = 2; p.KW = 2; p.stride = 1; p.pad = 0; p.Ktot = 4 * C0s + 9 * C1s; p.M = B * H2 * W2;
+  p.act = 0; p.shuffle = 0;
+  const int id = up2_pick_tile(p.M, ldy);
+  if (stats && (p.M % kTiles[id].bm)) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch (id) {
+    case 0: return launch_conv<2, 2, 4, 1, true>(p, st);
+    case 1: return launch_conv<2, 3, 4, 1, true>(p, st);
+    case 2: return launch_conv<2, 4, 4, 1, true>(p, st);
+    case 3: return launch_conv<2, 5, 4, 1, true>(p, st);
+    case 4: return launch_conv<4, 3, 2, 2, true>(p, st);
+    case 5: return launch_conv<4, 4, 2, 2, true>(p, st);
+    case 6: return launch_conv<2, 9, 4, 1, true>(p, st);
+    case 7: return launch_conv<4, 5, 2, 2, true>(p, st);
+    case 8: return launch_conv<1, 2, 4, 1, true>(p, st);
+    case 9: return launch_conv<1, 4, 4, 1, true>(p, st);
+    case 10: return launch_conv<2, 4, 2, 2, true>(p, st);
+    default: return launch_conv<1, 9, 4, 1, true>(p, st);
   }
 }
 

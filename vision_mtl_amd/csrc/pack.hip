@@ -174,6 +174,110 @@ extern "C" int vmtl_unpack_weights(const float* packed, float* grad, int R1, int
   return vmtl_check_launch();
 }
 
+// ------------------------------------------------------------------ up2 (upsample+concat+conv3x3) operands
+// Tap bookkeeping (see conv_igemm.hip, UP2): with output-row parity a and low-res tap ty, the 3x3 taps
+// dh that land on that low-res row are R(0,0)={0}, R(0,1)={1,2}, R(1,0)={0,1}, R(1,1)={2}.  For the
+// backward 4x4/stride-2/pad-1 convolution over dY, tap kh pairs with dh in {2-kh, 3-kh} (clipped to 0..2).
+__device__ __forceinline__ void up2_R(int a, int t, int& lo, int& hi) {
+  if (a == 0) { lo = t == 0 ? 0 : 1; hi = t == 0 ? 0 : 2; }
+  else { lo = t == 0 ? 0 : 2; hi = t == 0 ? 1 : 2; }
+}
+
+// dst[phase][n][kk]: kk < 4*C0s -> (ty,tx,c) summed taps; kk >= 4*C0s -> (tap, cj) plain copy of the skip channels
+__global__ __launch_bounds__(256) void pack_up2_fwd_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                                           int Cout, int C0, int C0s, int C1, int C1s,
+                                                           long long total) {
+  const int Cin = C0 + C1, Ktot = 4 * C0s + 9 * C1s;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % Ktot);
+    const long long rest = i / Ktot;
+    const int n = (int)(rest % Cout), phase = (int)(rest / Cout);
+    const int a = phase >> 1, b = phase & 1;
+    float v = 0.f;
+    const float* wn = w + (size_t)n * Cin * 9;
+    if (kk < 4 * C0s) {
+      const int t2 = kk / C0s, c = kk - t2 * C0s;
+      if (c < C0) {
+        int hl, hh, wl, wh;
+        up2_R(a, t2 >> 1, hl, hh);
+        up2_R(b, t2 & 1, wl, wh);
+        for (int dh = hl; dh <= hh; ++dh)
+          for (int dw = wl; dw <= wh; ++dw) v += wn[c * 9 + dh * 3 + dw];
+      }
+    } else {
+      const int k2 = kk - 4 * C0s;
+      const int tap = k2 / C1s, c = k2 - tap * C1s;
+      if (c < C1) v = wn[(C0 + c) * 9 + tap];
+    }
+    dst[i] = v;
+  }
+}
+
+// data-gradient operand of the low-res input: dst[c][(kh*4+kw)*Cos + n] = sum of W[n][c][dh][dw] over the
+// (dh, dw) paired with (kh, kw); rows c < C0 (4x4 / stride 2 / pad 1 convolution over dY)
+__global__ __launch_bounds__(256) void pack_up2_dgrad_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                                             int Cout, int Cos, int C0, int Cin, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Cos);
+    long long rest = i / Cos;
+    const int pos = (int)(rest % 16), c = (int)(rest / 16);
+    const int kh = pos >> 2, kw = pos & 3;
+    float v = 0.f;
+    if (n < Cout)
+      for (int dh = max(0, 2 - kh); dh <= min(2, 3 - kh); ++dh)
+        for (int dw = max(0, 2 - kw); dw <= min(2, 3 - kw); ++dw) v += w[((size_t)n * Cin + c) * 9 + dh * 3 + dw];
+    dst[i] = v;
+  }
+}
+
+// folds the slabs of the low-res weight gradient G[z][c][(kh*4+kw)*Cos + n] back onto the 3x3 taps:
+// dW[n][c][dh][dw] = sum_z sum_{kh in {2-dh,3-dh}} sum_{kw in {2-dw,3-dw}} G[z][c][kh][kw][n]   (c < C0)
+__global__ __launch_bounds__(256) void unpack_up2_kernel(const float* __restrict__ slabs, float* __restrict__ grad,
+                                                         int Cout, int Cos, int C0, int Cin, int nslabs,
+                                                         long long slab_stride, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Cout);
+    long long rest = i / Cout;
+    const int tap = (int)(rest % 9), c = (int)(rest / 9);
+    const int dh = tap / 3, dw = tap - dh * 3;
+    float s = 0.f;
+    for (int z = 0; z < nslabs; ++z) {
+      const float* g = slabs + (size_t)z * slab_stride + (size_t)c * 16 * Cos + n;
+      s += (g[((2 - dh) * 4 + (2 - dw)) * Cos] + g[((2 - dh) * 4 + (3 - dw)) * Cos]) +
+           (g[((3 - dh) * 4 + (2 - dw)) * Cos] + g[((3 - dh) * 4 + (3 - dw)) * Cos]);
+    }
+    grad[((size_t)n * Cin + c) * 9 + tap] = s;
+  }
+}
+
+extern "C" int vmtl_pack_up2_fwd(const float* w, float* dst, int Cout, int C0, int C0s, int C1, int C1s, void* stream) {
+  if (!w || !dst || Cout <= 0 || C0 <= 0 || C0 > C0s || C1 < 0 || C1 > C1s) return VMTL_ERR_ARG;
+  const long long total = 4ll * Cout * (4 * C0s + 9 * C1s);
+  hipLaunchKernelGGL(pack_up2_fwd_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, C0,
+                     C0s, C1, C1s, total);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_pack_up2_dgrad(const float* w, float* dst, int Cout, int Cos, int C0, int Cin, void* stream) {
+  if (!w || !dst || Cout <= 0 || Cout > Cos || C0 <= 0 || C0 > Cin) return VMTL_ERR_ARG;
+  const long long total = (long long)C0 * 16 * Cos;
+  hipLaunchKernelGGL(pack_up2_dgrad_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cos,
+                     C0, Cin, total);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_unpack_up2(const float* slabs, float* grad, int Cout, int Cos, int C0, int Cin, int nslabs,
+                               void* stream) {
+  if (!slabs || !grad || Cout <= 0 || Cout > Cos || C0 <= 0 || C0 > Cin || nslabs <= 0) return VMTL_ERR_ARG;
+  const long long total = (long long)C0 * 9 * Cout;
+  hipLaunchKernelGGL(unpack_up2_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, slabs, grad, Cout,
+                     Cos, C0, Cin, nslabs, (long long)C0 * 16 * Cos, total);
+  return vmtl_check_launch();
+}
+
 // ------------------------------------------------------------------ fused Adam over a flat arena
 // step_ptr[0] holds the (already incremented) step count as a float so the update can sit in a hipGraph.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,

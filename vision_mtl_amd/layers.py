@@ -107,6 +107,15 @@ def up2_cat(x: Act, skip: Act | None) -> Act:
     return Act(ops.concat2(x.t, x.C, skip.t, skip.C, up_a=2), x.C + skip.C)
 
 
+def up2_conv_bn_act(x: Act, skip: Act | None, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int) -> Act:
+    """act(BN(conv3x3(cat[nearest_x2(x), skip]))) - smp DecoderBlock entry - through the phase-decomposed
+    kernel (no upsampled / concatenated tensor, 4 instead of 9 taps on the upsampled channels)."""
+    if _pair(c.kernel_size) != 3 or _pair(c.padding) != 1 or _pair(c.stride) != 1 or c.bias is not None:
+        raise ValueError("up2_conv_bn_act expects a 3x3 / pad 1 / stride 1 conv without bias")
+    y, stats = ops.up2_conv(x.t, x.C, None if skip is None else skip.t, c.weight, want_stats=bn.training)
+    return bn_act(Act(y, c.out_channels), bn, act, None, None, stats)
+
+
 def maxpool2(x: Act) -> Act:
     return Act(ops.maxpool2(x.t), x.C)
 

@@ -212,8 +212,7 @@ class DecoderBlock(nn.Module):
         self.attention2 = Attention()
 
     def run(self, x: L.Act, skip: t.Optional[L.Act]) -> L.Act:
-        y = L.up2_cat(x, skip)
-        y = L.conv_bn_act(y, self.conv1[0], self.conv1[1], ACT_RELU)
+        y = L.up2_conv_bn_act(x, skip, self.conv1[0], self.conv1[1], ACT_RELU)  # nearest x2 + cat + conv + BN + ReLU
         return L.conv_bn_act(y, self.conv2[0], self.conv2[1], ACT_RELU)
 
 

@@ -41,9 +41,11 @@ def _req(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
 _RECORD = None  # bench.py sets this to a list to capture the GEMM-kernel launches of one step
 
 
-def _k(name, _flop=None, **kw):
+def _k(name, _flop=None, _xflop=None, **kw):
     if _RECORD is not None and _flop is not None:
-        _RECORD.append((name, dict(kw), float(_flop)))  # _flop: algorithmic FLOPs (logical channels)
+        # _flop: algorithmic FLOPs of the reference formulation (logical channels); _xflop: FLOPs the launch
+        # really executes when an algebraic rewrite makes them differ (up2_conv)
+        _RECORD.append((name, dict(kw), float(_flop), float(_flop if _xflop is None else _xflop)))
     lib().callk(name, stream=_stream(), **kw)
 
 
@@ -143,11 +145,11 @@ def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None, 
     return grad
 
 
-def _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Nw, KH, KW, stride, pad, flop):
+def _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Nw, KH, KW, stride, pad, flop, xflop=None):
     """Weight-gradient slabs [splits][Nw][KH*KW*Cs] (summed later by unpack)."""
     splits = lib().raw("vmtl_conv2d_wgrad_splits")(B * Ho * Wo, Nw, KH * KW * Cs)
     slabs = _empty((splits, Nw, KH * KW * Cs), x)
-    _k("vmtl_conv2d_wgrad", _flop=flop, x=x, dy=dy, slabs=slabs, splits=splits, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo,
+    _k("vmtl_conv2d_wgrad", _flop=flop, _xflop=xflop, x=x, dy=dy, slabs=slabs, splits=splits, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo,
        ldy=ldy, Nw=Nw, KH=KH, KW=KW, stride=stride, pad=pad)
     return slabs, splits
 
@@ -160,9 +162,10 @@ def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
     return out
 
 
-def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0, cin=None):
+def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0, cin=None,
+                 algo_flop=None):
     flop = 2.0 * B * Ho * Wo * Nw * KH * KW * (Cs if cin is None else cin)
-    _k("vmtl_conv2d_fwd", _flop=flop, x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
+    _k("vmtl_conv2d_fwd", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
        Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act=0, shuffle=shuffle)
 
 
@@ -227,6 +230,94 @@ class _Conv2d(torch.autograd.Function):
             if ctx.slots[1] is not None:
                 db = None
         return dx, dw, db, None, None, None
+
+
+class _Up2Conv(torch.autograd.Function):
+    """conv3x3(pad 1, no bias)(cat[nearest_x2(xl), skip]) - the entry of every smp U-Net decoder block
+    (reference utils/model_utils.py:25-34) - without materialising the upsample or the concat and with 4
+    instead of 9 taps on the upsampled channels (four 2x2 phase convolutions on the low-res map).
+    weight keeps the torch layout (Cout, C0 + C1, 3, 3), input channels ordered [xl | skip]."""
+
+    @staticmethod
+    def forward(ctx, xl, skip, weight, C0, want_stats):
+        xl, weight = _req(xl, "xl"), _req(weight, "weight")
+        B, H2, W2, C0s = xl.shape
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if tuple(weight.shape[2:]) != (3, 3):
+            raise ValueError("up2_conv: 3x3 kernels only")
+        if skip is not None:
+            skip = _req(skip, "skip")
+            C1s = skip.shape[3]
+            if tuple(skip.shape[:3]) != (B, 2 * H2, 2 * W2):
+                raise ValueError("up2_conv: skip must be at twice the resolution of xl")
+        else:
+            C1s = 0
+        C1 = Cin - C0
+        if ceil4(C0) != C0s or ceil4(C1) != C1s or (C1 > 0) != (skip is not None):
+            raise ValueError(f"up2_conv: weight has {Cin} input channels, sources hold {C0s}+{C1s} storage channels")
+        ldy = ceil4(Cout)
+        Ktot = 4 * C0s + 9 * C1s
+        wp = _empty((4, Cout, Ktot), xl)
+        _k("vmtl_pack_up2_fwd", w=weight, dst=wp, Cout=Cout, C0=C0, C0s=C0s, C1=C1, C1s=C1s)
+        y = _empty((B, 2 * H2, 2 * W2, ldy), xl)
+        stats = None
+        if want_stats:
+            bm = lib().raw("vmtl_conv2d_up2_stats_block")(B, H2, W2, ldy)
+            Mq = B * H2 * W2
+            if Mq % bm == 0:
+                stats = _empty((4 * (Mq // bm), 2, ldy), xl)
+        M = B * 4 * H2 * W2
+        # algorithmic FLOPs = the reference formulation (9 taps on every channel); executed: 4 taps on xl's
+        _k("vmtl_conv2d_up2_fwd", _flop=2.0 * M * Cout * 9 * Cin, _xflop=2.0 * M * Cout * (4 * C0 + 9 * C1), xl=xl,
+           skip=skip, wp_eff=wp, y=y, stats=stats, B=B, H2=H2, W2=W2, C0s=C0s, C1s=C1s, ldy=ldy, Cout=Cout)
+        ctx.save_for_backward(xl, skip, weight)
+        ctx.cfg = (C0, C1, stats.shape[0] if stats is not None else 0)
+        ctx.slot = _slot(weight)
+        ctx.set_materialize_grads(False)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        xl, skip, weight = ctx.saved_tensors
+        C0, C1, _ = ctx.cfg
+        if dy is None:
+            return None, None, None, None
+        dy = _req(dy, "dy")
+        B, H2, W2, C0s = xl.shape
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        H, W, ldy = 2 * H2, 2 * W2, dy.shape[3]
+        dxl = dskip = dw = None
+        if ctx.needs_input_grad[0]:  # 4x4 / stride 2 / pad 1 convolution over dY with pre-summed taps
+            wd = _empty((C0, 16 * ldy), xl)
+            _k("vmtl_pack_up2_dgrad", w=weight, dst=wd, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin)
+            dxl = _empty((B, H2, W2, C0s), xl)
+            _conv_launch(dy, wd, None, dxl, None, B, H, W, ldy, H2, W2, C0s, C0, C0, 4, 4, 2, 1, cin=Cout,
+                         algo_flop=2.0 * B * H * W * C0 * 9 * Cout)
+        if skip is not None and ctx.needs_input_grad[1]:  # plain 3x3 data gradient restricted to the skip channels
+            C1s = skip.shape[3]
+            wds = pack(weight.view(-1)[C0 * 9:], 1, C1, 9, Cout, ldy, 0, 9, 1, Cin * 9, flip=1)
+            dskip = _empty((B, H, W, C1s), xl)
+            _conv_launch(dy, wds, None, dskip, None, B, H, W, ldy, H, W, C1s, C1, C1, 3, 3, 1, 1, cin=Cout)
+        if ctx.needs_input_grad[2]:
+            dw = _empty(weight.shape, xl) if ctx.slot is None else ctx.slot
+            # low-res part: weight gradient of that 4x4/s2/p1 convolution (dY in the role of its input)
+            slabs, ns = _wgrad(dy, xl, B, H, W, ldy, H2, W2, C0s, C0, 4, 4, 2, 1, 2.0 * B * H * W * Cout * 9 * C0,
+                               xflop=2.0 * B * H2 * W2 * C0 * 16 * Cout)
+            _k("vmtl_unpack_up2", slabs=slabs, grad=dw, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin, nslabs=ns)
+            if skip is not None:
+                C1s = skip.shape[3]
+                slabs, ns = _wgrad(skip, dy, B, H, W, C1s, H, W, ldy, Cout, 3, 3, 1, 1, 2.0 * B * H * W * Cout * 9 * C1)
+                unpack(slabs, None, 1, Cout, 9, C1, C1s, 0, Cin * 9, 1, 9, out=dw.view(-1)[C0 * 9:], nslabs=ns)
+            if ctx.slot is not None:
+                dw = None
+        return dxl, dskip, dw, None, None
+
+
+def up2_conv(xl, C0, skip, weight, want_stats=False):
+    """(y, stats) = conv3x3(cat[nearest_x2(xl), skip]); C0 = logical channels of xl; stats may be None."""
+    return _Up2Conv.apply(xl, skip, weight, C0, want_stats)
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False):
