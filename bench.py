@@ -90,7 +90,7 @@ def time_conv_kernels(module, batch, reps=3):
         if os.environ.get("VMTL_CONV_TABLE") and "Ho" in kw:
             M = kw["B"] * kw["Ho"] * kw["Wo"]
             log(f"{name[12:]:6s} M={M:8d} N={kw['Nw']:5d} K={kw['KH'] * kw['KW'] * kw['Cs']:6d} "
-                f"k{kw['KH']}s{kw['stride']} {ms * 1e3:9.1f} us {flop / ms / 1e9:7.1f} TF")
+                f"k{kw['KH']}s{kw['stride']} {ms * 1e3:9.1f} us {flop / ms / 1e9:7.1f} TF (executed {xflop / ms / 1e9:6.1f})")
     return fam
 
 

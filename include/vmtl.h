@@ -43,6 +43,10 @@ const char* vmtl_version(void);
 int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
                     int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
                     int KH, int KW, int stride, int pad, int act, int shuffle, void* stream);
+/* split-K form for plain contractions (data gradients): ws = vmtl_conv2d_ksplit(...)*B*Ho*Wo*ldy floats */
+int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot);
+int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int B, int H, int W, int Cs,
+                       int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride, int pad, void* stream);
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
 int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
 

@@ -53,6 +53,9 @@ struct ConvP {
   // be null); wp holds 4 phase matrices [4][Nw][Ktot], Ktot = 4*Cs + 9*C2s; M = B*H*W rows per phase.
   const float* x2;
   int C2s;
+  // split-K (launches without bias / activation / stats / shuffle only): blockIdx.y = K slice, every
+  // slice writes its partial tile to ksl_out + slice * M * ldy; vmtl_sum_slabs adds them into y.
+  int ksplit, ksteps_per_split;
 };
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false>
@@ -175,7 +178,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.Ktot + BK - 1) / BK;
+  int nk = (p.Ktot + BK - 1) / BK;
+  if (p.ksplit > 1) {  // this workgroup's K slice: skip ahead, then run ksteps_per_split chunks
+    const int k_begin = blockIdx.y * p.ksteps_per_split;
+    nk = min(nk - k_begin, p.ksteps_per_split);
+    kk += k_begin * BK;
+    ci += k_begin * BK;
+    normalize();
+  }
   load_tile();
   store_tile(0);
   __syncthreads();
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // ---- epilogue: bias + activation, zero the pad channels, store ----
   // C layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int hw = p.Ho * p.Wo;
+  float* yout = p.ksplit > 1 ? p.y + (size_t)blockIdx.y * p.M * p.ldy : p.y;
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         } else if (!p.shuffle) {
           if (n < p.ldy) {
             if (n >= p.Cout) v = 0.f;
-            p.y[(size_t)m * p.ldy + n] = v;
+            yout[(size_t)m * p.ldy + n] = v;
           }
         } else if (n < p.Nw) {
           const int q = n / p.Cout, co = n - q * p.Cout;
@@ -547,8 +558,33 @@ static int launch_conv(ConvP& p, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2>), dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1),
+                     dim3(256), lds, st, p);
   return vmtl_check_launch();
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ y,
+                                                        int nslabs, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int z = 1; z < nslabs; ++z) s += reinterpret_cast<const f32x4*>(slabs)[(size_t)z * n4 + i];
+    reinterpret_cast<f32x4*>(y)[i] = s;
+  }
+}
+
+// K slices a forward/dgrad launch of this shape would use (1 = none).  Only launches without
+// bias/activation/stats/shuffle are split; the caller then passes a workspace of
+// splits * B*Ho*Wo * ldy floats (vmtl_conv2d_fwd_ws) and the partial tiles are summed in slice order.
+extern "C" int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot) {
+  const int M = B * Ho * Wo;
+  const int id = conv_pick_tile(M, ldy);
+  const long long blocks = (long long)cdiv(M, kTiles[id].bm) * cdiv(ldy, kTiles[id].bn);
+  const int nk = cdiv(Ktot, BK);
+  if (blocks >= 256 || nk < 32 || (ldy & 3)) return 1;
+  long long s = cdivll(512, blocks);
+  if (s > 8) s = 8;
+  if (s > nk / 16) s = nk / 16;
+  return s < 2 ? 1 : (int)s;
 }
 
 extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
@@ -566,7 +602,7 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats;
   p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
-  p.act = act; p.shuffle = shuffle; p.x2 = nullptr; p.C2s = 0;
+  p.act = act; p.shuffle = shuffle; p.x2 = nullptr; p.C2s = 0; p.ksplit = 1; p.ksteps_per_split = 0;
   hipStream_t st = (hipStream_t)stream;
   if (shuffle && ldy > Cout &&  // the scatter only writes co < Cout: keep the pad-channel invariant
       hipMemsetAsync(y, 0, (size_t)B * 4 * Ho * Wo * ldy * sizeof(float), st) != hipSuccess)
@@ -585,6 +621,47 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
     case 10: return launch_conv<2, 4, 2, 2>(p, st);
     default: return launch_conv<1, 9, 4, 1>(p, st);
   }
+}
+
+// split-K form of vmtl_conv2d_fwd for plain contractions (no bias / act / stats / shuffle): `ws` holds
+// vmtl_conv2d_ksplit(...) * B*Ho*Wo*ldy floats.  With ksplit == 1 it is exactly vmtl_conv2d_fwd.
+extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int B, int H, int W, int Cs,
+                                  int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride, int pad,
+                                  void* stream) {
+  const int splits = vmtl_conv2d_ksplit(B, Ho, Wo, ldy, KH * KW * Cs);
+  if (splits <= 1 || ws == nullptr)
+    return vmtl_conv2d_fwd(x, wp, nullptr, y, nullptr, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, 0, 0, stream);
+  if (!x || !wp || !y || Cs <= 0 || (Cs & 3) || Nw > ldy || Cout > ldy) return VMTL_ERR_ARG;
+  if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return VMTL_ERR_ARG;
+  ConvP p;
+  p.x = x; p.wp = wp; p.bias = nullptr; p.y = ws; p.stats = nullptr; p.x2 = nullptr; p.C2s = 0;
+  p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
+  p.act = 0; p.shuffle = 0;
+  p.ksplit = splits;
+  p.ksteps_per_split = cdiv(cdiv(p.Ktot, BK), splits);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  switch (conv_pick_tile(p.M, ldy)) {
+    case 0: rc = launch_conv<2, 2, 4, 1>(p, st); break;
+    case 1: rc = launch_conv<2, 3, 4, 1>(p, st); break;
+    case 2: rc = launch_conv<2, 4, 4, 1>(p, st); break;
+    case 3: rc = launch_conv<2, 5, 4, 1>(p, st); break;
+    case 4: rc = launch_conv<4, 3, 2, 2>(p, st); break;
+    case 5: rc = launch_conv<4, 4, 2, 2>(p, st); break;
+    case 6: rc = launch_conv<2, 9, 4, 1>(p, st); break;
+    case 7: rc = launch_conv<4, 5, 2, 2>(p, st); break;
+    case 8: rc = launch_conv<1, 2, 4, 1>(p, st); break;
+    case 9: rc = launch_conv<1, 4, 4, 1>(p, st); break;
+    case 10: rc = launch_conv<2, 4, 2, 2>(p, st); break;
+    default: rc = launch_conv<1, 9, 4, 1>(p, st); break;
+  }
+  if (rc) return rc;
+  const long long n4 = (long long)p.M * ldy / 4;
+  long long nb = cdivll(n4, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((int)nb), dim3(256), 0, st, ws, y, splits, n4);
+  return vmtl_check_launch();
 }
 
 // ---- nearest-x2 upsample + concat + 3x3 conv as four 2x2 phase convolutions ------------------------
@@ -618,7 +695,7 @@ extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const flo
   p.x = xl; p.x2 = skip; p.wp = wp_eff; p.bias = nullptr; p.y = y; p.stats = stats;
   p.B = B; p.H = H2; p.W = W2; p.Cs = C0s; p.C2s = C1s; p.Ho = H2; p.Wo = W2; p.ldy = ldy; p.Nw = Cout;
   p.Cout = Cout; p.KH = 2; p.KW = 2; p.stride = 1; p.pad = 0; p.Ktot = 4 * C0s + 9 * C1s; p.M = B * H2 * W2;
-  p.act = 0; p.shuffle = 0;
+  p.act = 0; p.shuffle = 0; p.ksplit = 1; p.ksteps_per_split = 0;
   const int id = up2_pick_tile(p.M, ldy);
   if (stats && (p.M % kTiles[id].bm)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

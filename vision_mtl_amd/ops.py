@@ -165,6 +165,14 @@ def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
 def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0, cin=None,
                  algo_flop=None):
     flop = 2.0 * B * Ho * Wo * Nw * KH * KW * (Cs if cin is None else cin)
+    if bias is None and stats is None and not shuffle:
+        # plain contraction (data gradients): split K when the tile grid alone cannot fill the chip
+        ks = lib().raw("vmtl_conv2d_ksplit")(B, Ho, Wo, ldy, KH * KW * Cs)
+        if ks > 1:
+            ws = _empty((ks, B * Ho * Wo, ldy), x)
+            _k("vmtl_conv2d_fwd_ws", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, y=y, ws=ws,
+               B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad)
+            return
     _k("vmtl_conv2d_fwd", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
        Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act=0, shuffle=shuffle)
 
