@@ -31,6 +31,10 @@ CONV_CASES = [
     (2, 192, 8, 8, 128, 1, 1, 0, True),     # MTAN attention 1x1
     (4, 16, 6, 10, 64, 1, 1, 0, False),     # pointwise expand
     (5, 960, 1, 1, 240, 1, 1, 0, True),     # SE reduce on a (B,1,1,C) map
+    # enough row tiles for the 128-row configurations with VALU tail columns (33 = 32+1, 20 = 16+4, 67 = 64+3)
+    (4, 33, 112, 112, 33, 3, 1, 1, True),
+    (4, 19, 112, 112, 20, 3, 1, 1, False),
+    (2, 37, 160, 160, 67, 3, 1, 1, False),
 ]
 
 
@@ -78,6 +82,40 @@ def test_conv2d_fwd_bwd(dev, case):
             assert xd.grad[..., Cin:].abs().max().item() == 0.0
     if bias:
         assert_close(bd.grad.cpu(), br.grad, what="conv bias grad")
+
+
+@pytest.mark.parametrize("tile", list(range(15)))
+def test_conv2d_every_tile_config(dev, tile, monkeypatch):
+    """Each implicit-GEMM tile configuration (ids in conv_igemm.hip, incl. the tail-column ones) forced
+    through the tuning override on one ragged shape: values, pad zeros, BatchNorm partials, data gradient."""
+    ops = _ops()
+    from vision_mtl_amd._lib import lib
+
+    monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
+    B, Cin, H, W, Cout = 3, 37, 21, 19, 70
+    g = torch.Generator().manual_seed(900 + tile)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    y, stats = ops.conv2d(xd, w.to(dev), None, stride=1, pad=1, want_stats=True)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what=f"tile {tile} fwd")
+    assert y[..., Cout:].abs().max().item() == 0.0
+    M = B * H * W
+    rpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, y.shape[-1])
+    st = stats.double().cpu()
+    nb = torch.tensor([max(0, min(rpb, M - b * rpb)) for b in range(st.shape[0])], dtype=torch.float64)[:, None]
+    mean = (nb * st[:, 0]).sum(0) / M
+    var = (st[:, 1] + nb * (st[:, 0] - mean) ** 2).sum(0) / M
+    yo = yr.detach().double()
+    assert_close(mean[:Cout], yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what=f"tile {tile} stats mean")
+    assert_close(var[:Cout], yo.var((0, 2, 3), unbiased=False), tol=1e-4, what=f"tile {tile} stats var")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, Cin), xr.grad, what=f"tile {tile} dgrad")
+    assert xd.grad[..., Cin:].abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
@@ -130,8 +168,19 @@ def test_dwconv(dev, case):
 
 
 @pytest.mark.parametrize("case", [(2, 135, 16, 4, 6, 67), (1, 960, 112, 3, 5, 540), (2, 67, 0, 8, 8, 33),
-                                  (3, 270, 24, 5, 3, 135), (2, 20, 7, 1, 1, 9)])
+                                  (3, 270, 24, 5, 3, 135), (2, 20, 7, 1, 1, 9),
+                                  (2, 40, 8, 80, 80, 33), (1, 24, 6, 112, 112, 67)])  # tail-column tiles
 def test_up2_conv(dev, case):
+    _check_up2(dev, case)
+
+
+@pytest.mark.parametrize("tile", [0, 3, 5, 9, 12, 13, 14])
+def test_up2_conv_forced_tile(dev, tile, monkeypatch):
+    monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
+    _check_up2(dev, (2, 24, 6, 10, 12, 35))
+
+
+def _check_up2(dev, case):
     """Phase-decomposed decoder-block entry == conv3x3(cat[nearest_x2(x), skip]) (values, fused BatchNorm
     partials, and the gradients of x, skip and the weight)."""
     ops = _ops()

@@ -58,13 +58,19 @@ struct ConvP {
   int ksplit, ksteps_per_split;
 };
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false>
+// NT > 0: the last NT output columns of the tile ("tail") are not given an MFMA tile of their own; every
+// lane dots its A fragment (already in registers) with the tail weight rows on the VALU.  With 33 / 20 /
+// 67 output channels this keeps the MFMA tiles at 32 / 16 / 64 useful columns instead of padding to
+// 48 / 32 / 80 (the VALU pipe is otherwise idle next to the matrix pipe).  Needs WAVES_N == 1.
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false, int NT = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = WAVES_M * TM * 16;
-  constexpr int BN = WAVES_N * TN * 16;
-  constexpr int RA = (BM + 31) / 32;  // A rows per loader thread
-  constexpr int RB = (BN + 31) / 32;  // B rows per loader thread
+  constexpr int BNM = WAVES_N * TN * 16;  // columns covered by MFMA tiles
+  constexpr int BN = BNM + NT;            // + tail columns
+  constexpr int RA = (BM + 31) / 32;      // A rows per loader thread
+  constexpr int RB = (BN + 31) / 32;      // B rows per loader thread
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(NT == 0 || WAVES_N == 1, "tail columns need all waves to span the full tile width");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][BM][LDT]
@@ -177,6 +183,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float tacc[TM][NT > 0 ? NT : 1];  // tail columns: per-lane partial dot products over this lane's k quads
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < (NT > 0 ? NT : 1); ++t) tacc[i][t] = 0.f;
 
   int nk = (p.Ktot + BK - 1) / BK;
   if (p.ksplit > 1) {  // this workgroup's K slice: skip ahead, then run ksteps_per_split chunks
@@ -212,6 +223,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+      if (NT > 0) {
+        // tail weight rows BNM + t (wave-uniform row, per-quarter k slot): 4 distinct LDS addresses
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 ft = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LDT + (BNM + t) * LDT +
+                                                           (((kg * 4 + lq) ^ ((BNM + t) & 7)) * 4));
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            tacc[i][t] += fa[i][0] * ft[0] + fa[i][1] * ft[1] + fa[i][2] * ft[2] + fa[i][3] * ft[3];
+        }
+      }
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -258,6 +280,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
   }
 
+  // ---- tail columns: fold the four k quarters, lanes of quarter 0 own one output row each ----
+  float tv[TM][NT > 0 ? NT : 1];
+  if (NT > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float v = tacc[i][t];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int n = n0 + BNM + t;
+        const int m = m0 + (wm * TM + i) * 16 + l15;
+        const float bt = (p.bias != nullptr && n < p.Nw) ? p.bias[n] : 0.f;
+        v = (n < p.Cout) ? act_fwd(v + bt, p.act) : 0.f;
+        tv[i][t] = v;
+        if (lq == 0 && m < p.M && n < p.ldy) {
+          if (UP2) {
+            const int b_ = m / hw, rem = m - b_ * hw;
+            const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
+            p.y[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
+          } else {
+            yout[(size_t)m * p.ldy + n] = v;
+          }
+        }
+      }
+  }
+
   // ---- BatchNorm partials of this row block, straight from the accumulators: per column the
   // block-local MEAN and M2 = sum (v - mean)^2 (two in-register passes).  The finalize kernel
   // merges blocks with Chan's parallel-variance formula in fp64, so the variance never goes
@@ -285,6 +334,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       s1 += __shfl_xor(s1, 32, 64);
       if (lq == 0) red[wm * BN + (wn * TN + j) * 16 + l15] = s1;
     }
+    if (NT > 0) {  // tail columns: lanes of quarter 0 hold one row each -> fold the 16 rows of the tile
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          if (m0 + (wm * TM + i) * 16 + l15 < p.M) s1 += tv[i][t];
+        s1 += __shfl_xor(s1, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64);
+        s1 += __shfl_xor(s1, 4, 64);
+        s1 += __shfl_xor(s1, 8, 64);
+        if (lane == 0) red[wm * BN + BNM + t] = s1;
+      }
+    }
     __syncthreads();
     float mean[TN];
 #pragma unroll
@@ -293,6 +356,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + (wn * TN + j) * 16 + l15];
       mean[j] = s / (float)nvalid;
+    }
+    if (NT > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + BNM + t];
+        const float mt = s / (float)nvalid;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          if (m0 + (wm * TM + i) * 16 + l15 < p.M) s2 += (tv[i][t] - mt) * (tv[i][t] - mt);
+        s2 += __shfl_xor(s2, 1, 64);
+        s2 += __shfl_xor(s2, 2, 64);
+        s2 += __shfl_xor(s2, 4, 64);
+        s2 += __shfl_xor(s2, 8, 64);
+        if (lane == 0) red[(WAVES_M + wm) * BN + BNM + t] = s2;
+      }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -502,21 +583,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 // host-side tile selection + launchers
 // ---------------------------------------------------------------------------
 struct TileCfg { int bm, bn; float eff; };
-// id -> <TM, TN, WAVES_M, WAVES_N>
+// id -> <TM, TN, WAVES_M, WAVES_N[, tail]>
 //  0 <2,2,4,1> 128x32    1 <2,3,4,1> 128x48    2 <2,4,4,1> 128x64    3 <2,5,4,1> 128x80
 //  4 <4,3,2,2> 128x96    5 <4,4,2,2> 128x128   6 <2,9,4,1> 128x144   7 <4,5,2,2> 128x160
 //  8 <1,2,4,1> 64x32     9 <1,4,4,1> 64x64    10 <2,4,2,2> 64x128   11 <1,9,4,1> 64x144
+// 12 <2,2,4,1,+4> 128x(32+4)   13 <2,1,4,1,+4> 128x(16+4)   14 <2,4,4,1,+4> 128x(64+4)   (VALU tail columns)
 // eff = measured MFMA-rate of the tile relative to the 144-wide one on MI355X (tools/bench_conv.py):
 // narrow tiles re-stage the A operand more often per MFMA.
 static const TileCfg kTiles[] = {{128, 32, 0.55f}, {128, 48, 0.72f}, {128, 64, 0.80f}, {128, 80, 0.88f},
                                  {128, 96, 0.92f}, {128, 128, 0.95f}, {128, 144, 1.0f}, {128, 160, 1.0f},
-                                 {64, 32, 0.50f},  {64, 64, 0.85f},  {64, 128, 0.75f},  {64, 144, 1.0f}};
+                                 {64, 32, 0.50f},  {64, 64, 0.85f},  {64, 128, 0.75f},  {64, 144, 1.0f},
+                                 {128, 36, 0.62f}, {128, 20, 0.43f}, {128, 68, 0.85f}};
+#define VMTL_NTILES 15
+static const int kBigIds[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14};
+static const int kSmallIds[] = {8, 9, 10, 11};
 
-static int pick_in(int lo, int hi, int ncols) {
+static int pick_from(const int* ids, int n, int ncols) {
   // minimise issued MFMA work / tile efficiency = (padded columns) / eff
-  int best = lo;
+  int best = ids[0];
   float best_cost = -1.f;
-  for (int id = lo; id < hi; ++id) {
+  for (int k = 0; k < n; ++k) {
+    const int id = ids[k];
     const float cost = (float)((long long)cdiv(ncols, kTiles[id].bn) * kTiles[id].bn) / kTiles[id].eff;
     if (best_cost < 0.f || cost < best_cost) {
       best = id;
@@ -529,11 +616,11 @@ static int pick_in(int lo, int hi, int ncols) {
 static int conv_pick_tile(int M, int ncols) {
   if (const char* f = getenv("VMTL_FORCE_TILE")) {  // tuning aid (tools/bench_conv.py), never set in production
     const int id = atoi(f);
-    if (id >= 0 && id < 12) return id;
+    if (id >= 0 && id < VMTL_NTILES) return id;
   }
-  const int big = pick_in(0, 8, ncols);
+  const int big = pick_from(kBigIds, 11, ncols);
   // too few workgroups for 256 CUs: halve the row block
-  if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_in(8, 12, ncols);
+  if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
   return big;
 }
 
@@ -546,19 +633,19 @@ extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
   return kTiles[conv_pick_tile(B * Ho * Wo, ldy)].bm;
 }
 
-template <int TM, int TN, int WMV, int WNV, bool UP2 = false>
+template <int TM, int TN, int WMV, int WNV, bool UP2 = false, int NT = 0>
 static int launch_conv(ConvP& p, hipStream_t st) {
-  constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16;
+  constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16 + NT;
   p.tiles_m = cdiv(p.M, BM) * (UP2 ? 4 : 1);
   p.tiles_n = cdiv(p.shuffle ? p.Nw : p.ldy, BN);
   const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2>), dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1),
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT>), dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1),
                      dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
@@ -619,7 +706,10 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
     case 8: return launch_conv<1, 2, 4, 1>(p, st);
     case 9: return launch_conv<1, 4, 4, 1>(p, st);
     case 10: return launch_conv<2, 4, 2, 2>(p, st);
-    default: return launch_conv<1, 9, 4, 1>(p, st);
+    case 11: return launch_conv<1, 9, 4, 1>(p, st);
+    case 12: return launch_conv<2, 2, 4, 1, false, 4>(p, st);
+    case 13: return launch_conv<2, 1, 4, 1, false, 4>(p, st);
+    default: return launch_conv<2, 4, 4, 1, false, 4>(p, st);
   }
 }
 
@@ -654,7 +744,10 @@ extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, flo
     case 8: rc = launch_conv<1, 2, 4, 1>(p, st); break;
     case 9: rc = launch_conv<1, 4, 4, 1>(p, st); break;
     case 10: rc = launch_conv<2, 4, 2, 2>(p, st); break;
-    default: rc = launch_conv<1, 9, 4, 1>(p, st); break;
+    case 11: rc = launch_conv<1, 9, 4, 1>(p, st); break;
+    case 12: rc = launch_conv<2, 2, 4, 1, false, 4>(p, st); break;
+    case 13: rc = launch_conv<2, 1, 4, 1, false, 4>(p, st); break;
+    default: rc = launch_conv<2, 4, 4, 1, false, 4>(p, st); break;
   }
   if (rc) return rc;
   const long long n4 = (long long)p.M * ldy / 4;
@@ -673,10 +766,10 @@ extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, flo
 static int up2_pick_tile(int Mq, int ncols) {
   if (const char* f = getenv("VMTL_FORCE_TILE")) {
     const int id = atoi(f);
-    if (id >= 0 && id < 12) return id;
+    if (id >= 0 && id < VMTL_NTILES) return id;
   }
-  const int big = pick_in(0, 8, ncols);
-  if ((long long)cdiv(Mq, 128) * 4 * cdiv(ncols, kTiles[big].bn) < 384) return pick_in(8, 12, ncols);
+  const int big = pick_from(kBigIds, 11, ncols);
+  if ((long long)cdiv(Mq, 128) * 4 * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
   return big;
 }
 
@@ -711,7 +804,10 @@ extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const flo
     case 8: return launch_conv<1, 2, 4, 1, true>(p, st);
     case 9: return launch_conv<1, 4, 4, 1, true>(p, st);
     case 10: return launch_conv<2, 4, 2, 2, true>(p, st);
-    default: return launch_conv<1, 9, 4, 1, true>(p, st);
+    case 11: return launch_conv<1, 9, 4, 1, true>(p, st);
+    case 12: return launch_conv<2, 2, 4, 1, true, 4>(p, st);
+    case 13: return launch_conv<2, 1, 4, 1, true, 4>(p, st);
+    default: return launch_conv<2, 4, 4, 1, true, 4>(p, st);
   }
 }
 
