@@ -48,6 +48,7 @@ class FlatArena:
 
     def all_reduce_mean(self):
         """Average the flat gradient over all ranks: one RCCL all-reduce."""
+        ops.side.join()  # no-op unless a backward pass ended abnormally with side-stream work un-joined
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
@@ -58,6 +59,7 @@ class FlatArena:
         if self._adam is None:
             z = torch.zeros_like(self.flat_param)
             self._adam = {"m": z, "v": z.clone(), "step": torch.zeros(1, dtype=torch.float32, device=z.device)}
+        ops.side.join()
         st = self._adam
         st["step"] += 1
         ops.adam_step(self.flat_param, self.flat_grad, st["m"], st["v"], st["step"], lr, betas, eps, weight_decay,

@@ -11,6 +11,9 @@ the calling module.
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import torch
 
 from ._lib import lib
@@ -65,6 +68,72 @@ def _reduce_rows(M: int) -> int:
     return lib().raw("vmtl_reduce_rows")(M)
 
 
+# ----------------------------------------------------------------------------- weight-gradient branch
+class _SideBranch:
+    """Second HIP stream for the parameter-gradient launches of the backward pass.
+
+    The data-gradient chain (dgrad -> BN backward -> dgrad ...) is the critical path of the backward pass;
+    the weight gradients hang off it as leaves whose results nobody needs before the optimizer /
+    all-reduce.  On the MobileNetV3 encoder those launches are small (tens of workgroups), so running
+    them on a second stream lets them fill CUs the critical path leaves idle.  Inside a hipGraph capture
+    the fork/join events become parallel graph branches.  Only used when the gradient goes to a
+    FlatArena slot (nothing is handed back to autograd, which would expect it on the main stream).
+    The side stream is joined by an end-of-backward engine callback (and by FlatArena before it reads
+    the gradient buffer).  VMTL_SIDE_STREAM=0 turns the branch off; VMTL_SIDE_MAX_ROWS bounds the GEMM
+    rows (pixels) of a launch that may leave the main stream."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("VMTL_SIDE_STREAM", "1") != "0"
+        self.max_rows = int(os.environ.get("VMTL_SIDE_MAX_ROWS", str(1 << 30)))
+        self.streams = {}
+        self.pending = None  # the side stream with un-joined work
+
+    def stream(self, device):
+        s = self.streams.get(device.index)
+        if s is None:
+            s = self.streams[device.index] = torch.cuda.Stream(device=device)
+        return s
+
+    def join(self):
+        s, self.pending = self.pending, None
+        if s is not None:
+            torch.cuda.current_stream(s.device).wait_stream(s)
+
+    def mark(self):
+        """Record the fork point on the current (main) stream.  Taken on entry of a backward function so the
+        branch depends on what was queued BEFORE the function's own main-stream launches, while those
+        launches are still issued first (inside a hipGraph capture the main-stream node then precedes the
+        branch node in creation order, which keeps the critical path on one hardware queue)."""
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    @contextlib.contextmanager
+    def branch(self, use, rows, mark, *tensors):
+        """Run the enclosed launches on the side stream, ordered after `mark`.  `tensors` are main-stream
+        tensors the launches read: the allocator must not recycle them for main-stream work until the
+        side stream is past these launches."""
+        if not (self.enabled and use and mark is not None and rows <= self.max_rows):
+            yield
+            return
+        main = torch.cuda.current_stream()
+        s = self.stream(main.device)
+        s.wait_event(mark)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(s)
+        if self.pending is None:
+            self.pending = s
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        with torch.cuda.stream(s):
+            yield
+
+
+side = _SideBranch()
+
+
 # ----------------------------------------------------------------------------- packing
 class _PackCache:
     """Packed GEMM operands of the model's weights, refreshed by ONE batched launch per step.
@@ -101,7 +170,12 @@ class _PackCache:
     def _build_table(self):
         import struct
 
-        live = [e for e in self.entries.values() if e["weight"].data_ptr() == e["ptr"]]
+        # entries whose weight moved (e.g. into a FlatArena) are dead: get() made fresh ones for the new storage
+        self.entries = {k: e for k, e in self.entries.items() if e["weight"].data_ptr() == e["ptr"]}
+        live = list(self.entries.values())
+        if not live:
+            self.table, self.live, self.dirty = None, [], False
+            return
         recs, start = [], 0
         for e in live:
             R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
@@ -123,6 +197,8 @@ class _PackCache:
             if torch.cuda.is_current_stream_capturing():
                 return  # keep per-call packing inside this capture; the table is rebuilt on the next eager step
             self._build_table()
+        if self.table is None:
+            return
         table, n, total = self.table
         _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
         for e in self.live:
@@ -221,6 +297,7 @@ class _Conv2d(torch.autograd.Function):
         KK = KH * KW
         _, Ho, Wo, ldy = dy.shape
         dx = dw = db = None
+        fork = side.mark()  # parameter gradients branch off here, before the data gradient
         if ctx.needs_input_grad[0]:
             if stride != 1:
                 raise NotImplementedError("data gradient of a strided dense conv is not on the hot path")
@@ -228,13 +305,15 @@ class _Conv2d(torch.autograd.Function):
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=Cout)
         if ctx.needs_input_grad[1]:
-            slabs, ns = _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Cout, KH, KW, stride, pad,
-                               2.0 * B * Ho * Wo * Cout * KK * Cin)
-            dw = unpack(slabs, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns)
+            with side.branch(ctx.slots[0] is not None, B * Ho * Wo, fork, x, dy):
+                slabs, ns = _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Cout, KH, KW, stride, pad,
+                                   2.0 * B * Ho * Wo * Cout * KK * Cin)
+                dw = unpack(slabs, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns)
             if ctx.slots[0] is not None:
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, None, B * Ho * Wo, Cout, ldy, out=ctx.slots[1])
+            with side.branch(ctx.slots[1] is not None, B * Ho * Wo, fork, dy):
+                db = _colsum(dy, None, B * Ho * Wo, Cout, ldy, out=ctx.slots[1])
             if ctx.slots[1] is not None:
                 db = None
         return dx, dw, db, None, None, None
@@ -297,6 +376,7 @@ class _Up2Conv(torch.autograd.Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         H, W, ldy = 2 * H2, 2 * W2, dy.shape[3]
         dxl = dskip = dw = None
+        fork = side.mark()
         if ctx.needs_input_grad[0]:  # 4x4 / stride 2 / pad 1 convolution over dY with pre-summed taps
             wd = _empty((C0, 16 * ldy), xl)
             _k("vmtl_pack_up2_dgrad", w=weight, dst=wd, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin)
@@ -310,14 +390,16 @@ class _Up2Conv(torch.autograd.Function):
             _conv_launch(dy, wds, None, dskip, None, B, H, W, ldy, H, W, C1s, C1, C1, 3, 3, 1, 1, cin=Cout)
         if ctx.needs_input_grad[2]:
             dw = _empty(weight.shape, xl) if ctx.slot is None else ctx.slot
-            # low-res part: weight gradient of that 4x4/s2/p1 convolution (dY in the role of its input)
-            slabs, ns = _wgrad(dy, xl, B, H, W, ldy, H2, W2, C0s, C0, 4, 4, 2, 1, 2.0 * B * H * W * Cout * 9 * C0,
-                               xflop=2.0 * B * H2 * W2 * C0 * 16 * Cout)
-            _k("vmtl_unpack_up2", slabs=slabs, grad=dw, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin, nslabs=ns)
-            if skip is not None:
-                C1s = skip.shape[3]
-                slabs, ns = _wgrad(skip, dy, B, H, W, C1s, H, W, ldy, Cout, 3, 3, 1, 1, 2.0 * B * H * W * Cout * 9 * C1)
-                unpack(slabs, None, 1, Cout, 9, C1, C1s, 0, Cin * 9, 1, 9, out=dw.view(-1)[C0 * 9:], nslabs=ns)
+            with side.branch(ctx.slot is not None, B * H * W, fork, dy, xl, skip):
+                # low-res part: weight gradient of that 4x4/s2/p1 convolution (dY in the role of its input)
+                slabs, ns = _wgrad(dy, xl, B, H, W, ldy, H2, W2, C0s, C0, 4, 4, 2, 1, 2.0 * B * H * W * Cout * 9 * C0,
+                                   xflop=2.0 * B * H2 * W2 * C0 * 16 * Cout)
+                _k("vmtl_unpack_up2", slabs=slabs, grad=dw, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin, nslabs=ns)
+                if skip is not None:
+                    C1s = skip.shape[3]
+                    slabs, ns = _wgrad(skip, dy, B, H, W, C1s, H, W, ldy, Cout, 3, 3, 1, 1,
+                                       2.0 * B * H * W * Cout * 9 * C1)
+                    unpack(slabs, None, 1, Cout, 9, C1, C1s, 0, Cin * 9, 1, 9, out=dw.view(-1)[C0 * 9:], nslabs=ns)
             if ctx.slot is not None:
                 dw = None
         return dxl, dskip, dw, None, None
@@ -362,17 +444,21 @@ class _ConvT2x2(torch.autograd.Function):
         Cin, Cout = weight.shape[0], weight.shape[1]
         ldy = dy.shape[3]
         dx = dw = db = None
+        fork = side.mark()
         if ctx.needs_input_grad[0]:  # a 2x2 / stride-2 conv over dy
             wd = packs.get(weight, "ct_bwd", (1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, 0))
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, Cin, 2, 2, 2, 0, cin=Cout)
         if ctx.needs_input_grad[1]:  # weight gradient of that same conv, with x in the role of its output gradient
-            slabs, ns = _wgrad(dy, x, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, 2, 2, 2, 0, 2.0 * B * H * W * Cin * 4 * Cout)
-            dw = unpack(slabs, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, out=ctx.slots[0], nslabs=ns)
+            with side.branch(ctx.slots[0] is not None, B * H * W, fork, x, dy):
+                slabs, ns = _wgrad(dy, x, B, 2 * H, 2 * W, ldy, H, W, Cs, Cin, 2, 2, 2, 0,
+                                   2.0 * B * H * W * Cin * 4 * Cout)
+                dw = unpack(slabs, weight.shape, 1, Cin, 4, Cout, ldy, 0, Cout * 4, 1, 4, out=ctx.slots[0], nslabs=ns)
             if ctx.slots[0] is not None:
                 dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, None, B * 4 * H * W, Cout, ldy, out=ctx.slots[1])
+            with side.branch(ctx.slots[1] is not None, B * 4 * H * W, fork, dy):
+                db = _colsum(dy, None, B * 4 * H * W, Cout, ldy, out=ctx.slots[1])
             if ctx.slots[1] is not None:
                 db = None
         return dx, dw, db
@@ -411,15 +497,17 @@ class _DwConv(torch.autograd.Function):
         C, _, K, _ = weight.shape
         _, Ho, Wo, _ = dy.shape
         dx = dw = None
+        fork = side.mark()
         if ctx.needs_input_grad[0]:
             dx = _empty(x.shape, x)
             _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=dx, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride,
                pad=pad)
         if ctx.needs_input_grad[1]:
-            partial = _empty((256, K * K, Cs), x)
-            dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
-            _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo,
-               K=K, stride=stride, pad=pad)
+            with side.branch(ctx.slot is not None, B * Ho * Wo, fork, x, dy):
+                partial = _empty((256, K * K, Cs), x)
+                dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
+                _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho,
+                   Wo=Wo, K=K, stride=stride, pad=pad)
             if ctx.slot is not None:
                 dw = None
         return dx, dw, None, None
