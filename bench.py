@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    from vision_mtl_amd import dp
+    from vision_mtl_amd import dp, ops
 
     rank, world, local_rank = dp.init_distributed()
     if world != args.gpus:
@@ -177,8 +177,11 @@ def main():
     import torch.distributed as dist
 
     def step():
+        ops.stamp("step start")
         loss = module.training_step(batch, 0)
+        ops.stamp("forward done")
         loss.backward()
+        ops.stamp("backward joined")
         return loss
 
     def after_step():
@@ -194,6 +197,8 @@ def main():
         torch.cuda.synchronize()
         log(f"eager warm-up step {i} done")
 
+    if os.environ.get("VMTL_STAMPS") == "1":  # two-stream timeline of one replayed step (tuning aid)
+        ops._STAMPS = []
     graph = None
     if not args.no_graph:
         side = torch.cuda.Stream()
@@ -231,6 +236,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if ops._STAMPS is not None and graph is not None:
+        stamps, ops._STAMPS = ops._STAMPS, None
+        n = len(stamps) // 2  # the pre-capture rehearsal step and the captured step both appended
+        graph.replay()
+        torch.cuda.synchronize()
+        vals = [(int(t.item()), tag) for tag, t in stamps[-n:]]
+        t0 = min(v for v, _ in vals)
+        for v, tag in sorted(vals):
+            log(f"stamp {(v - t0) / 100.0:10.1f} us  {tag}")
     loss_val = float((static_loss if graph is not None else step()).item())
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
 

@@ -29,6 +29,8 @@ extern "C" {
 #define VMTL_ACT_SIGMOID 4
 
 const char* vmtl_version(void);
+/* tuning aid: *out = 100 MHz device wall clock at the moment `stream` gets there */
+int vmtl_timestamp(long long* out, void* stream);
 
 /* ---- convolution (implicit GEMM on exact-fp32 MFMA) -------------------------------------
  * replaces nn.Conv2d / nn.ConvTranspose2d at utils/model_utils.py:71,74;
@@ -127,6 +129,26 @@ int vmtl_bilinear_up2_bwd(const float* dy, float* dx, int B, int H, int W, int C
 int vmtl_spatial_mean(const float* x, float* y, int B, int HW, int Cs, void* stream);
 int vmtl_channel_bcast(const float* x, const float* s, float* y, int B, int HW, int Cs, int mode, void* stream);
 int vmtl_channel_scale_bwd_s(const float* x, const float* dy, float* ds, int B, int HW, int Cs, void* stream);
+/* The squeeze-excite gate as batch-sized GEMMs (M = B <= vmtl_fc_max_rows() rows): the 1x1 convs of timm
+ * SqueezeExcite on a (B,1,1,C) map (encoder of models/basic_model.py:17-28).
+ * vmtl_fc_fwd: z = bias + A W^T, y = act(z); A = a_scale * sum_{s<a_parts} a[s] (partial sums of a spatial
+ *   reduction), optionally multiplied by act'(a_z) with activation a_act (data gradient with the activation
+ *   backward fused: pass the transposed weight as w).  w is [N][ldw] with K contiguous; z may be NULL.
+ * vmtl_fc_wgrad: dw[n][k] = sum_m dz[m][n] x[m][k], db[n] = sum_m dz[m][n], dz = (sum of dy parts) * act'(zo);
+ *   dw in the torch (N, K, 1, 1) layout.
+ * vmtl_hw_reduce: part[s][b][c] = sum over HW slice s of x (* y if given); S = vmtl_hw_reduce_parts(B,HW,Cs).
+ * vmtl_channel_scale_add: y = x * s[b][c] + t[b][c] * t_scale (t may be NULL). */
+int vmtl_fc_max_rows(void);
+int vmtl_fc_fwd(const float* a, int a_parts, long long a_part_stride, float a_scale, const float* a_z, int a_act,
+                const float* w, const float* bias, float* z, float* y, int M, int K, int N, int lda, int ldw, int ldy,
+                int act, void* stream);
+int vmtl_fc_wgrad(const float* x, int x_parts, long long x_part_stride, float x_scale, const float* dyo, int dy_parts,
+                  long long dy_part_stride, const float* zo, float* dw, float* db, int M, int K, int N, int lda, int ldn,
+                  int act, void* stream);
+int vmtl_hw_reduce_parts(int B, int HW, int Cs);
+int vmtl_hw_reduce(const float* x, const float* y, float* part, int B, int HW, int Cs, void* stream);
+int vmtl_channel_scale_add(const float* x, const float* s, const float* t, float t_scale, float* y, int B, int HW,
+                           int Cs, void* stream);
 /* models/cross_stitch_model.py:32-37 (diagonal of the 2x2 stitch matrix) */
 int vmtl_stitch(const float* x, const float* w, float* y, long long M, int C, int Cs, int wstride, void* stream);
 /* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */

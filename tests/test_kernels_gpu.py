@@ -431,6 +431,34 @@ def test_squeeze_excite_pieces(dev):
     assert_close(from_dev_nhwc(sd.grad, 72), sr.grad, what="se ds")
 
 
+@pytest.mark.parametrize("case", [(32, 72, 24, 16, 32), (3, 960, 240, 4, 8), (5, 120, 32, 9, 7), (64, 40, 10, 2, 2),
+                                  (17, 18, 7, 1, 1)])
+def test_squeeze_excite_fused(dev, case):
+    """ops.squeeze_excite (partial spatial sums -> two batch-sized GEMMs -> scale) == timm SqueezeExcite in
+    torch: x * hardsigmoid(conv_expand(relu(conv_reduce(mean_hw(x))))); values and all five gradients."""
+    ops = _ops()
+    B, C, R, H, W = case
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, C, H, W, generator=g)
+    wr, br = torch.randn(R, C, 1, 1, generator=g) / C ** 0.5, torch.randn(R, generator=g) * 0.5
+    we, be = torch.randn(C, R, 1, 1, generator=g) * (2.0 / R ** 0.5), torch.randn(C, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, wr, br, we, be)]
+    s = F.conv2d(F.relu(F.conv2d(ref[0].mean((2, 3), keepdim=True), ref[1], ref[2])), ref[3], ref[4])
+    yr = ref[0] * F.hardsigmoid(s)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    d = [t.to(dev).requires_grad_(True) for t in (wr, br, we, be)]
+    y = ops.squeeze_excite(xd, d[0], d[1], d[2], d[3])
+    assert_close(from_dev_nhwc(y, C), yr.detach(), what="se fwd")
+    if y.shape[-1] > C:
+        assert y[..., C:].abs().max().item() == 0.0
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), ref[0].grad, what="se dx")
+    for i, name in enumerate(["w_reduce", "b_reduce", "w_expand", "b_expand"]):
+        assert_close(d[i].grad.cpu(), ref[i + 1].grad, what=f"se d{name}")
+
+
 @pytest.mark.parametrize("channel_wise", [True, False])
 def test_stitch(dev, channel_wise):
     ops = _ops()

@@ -4,3 +4,13 @@
 #include "../../include/vmtl.h"
 
 extern "C" const char* vmtl_version(void) { return "vmtl 0.1 (gfx950)"; }
+
+// Timeline probe for tuning multi-stream schedules: writes the 100 MHz wall clock when the stream reaches it
+// (rocprofv3's kernel trace perturbs cross-queue overlap, a one-thread kernel barely does).
+__global__ void timestamp_kernel(long long* out) { *out = (long long)wall_clock64(); }
+
+extern "C" int vmtl_timestamp(long long* out, void* stream) {
+  if (!out) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out);
+  return vmtl_check_launch();
+}

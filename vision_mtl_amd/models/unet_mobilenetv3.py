@@ -75,6 +75,11 @@ class SqueezeExcite(nn.Module):
         self.gate = nn.Hardsigmoid()
 
     def run(self, x: L.Act) -> L.Act:
+        if x.t.shape[0] <= L.ops.squeeze_excite_max_batch():
+            # fused path: per-image partial sums -> two batch-sized GEMMs -> scale
+            y = L.ops.squeeze_excite(x.t, self.conv_reduce.weight, self.conv_reduce.bias, self.conv_expand.weight,
+                                     self.conv_expand.bias, ACT_RELU, ACT_HSIGMOID)
+            return L.Act(y, x.C)
         s = L.Act(L.ops.spatial_mean(x.t), x.C)
         s = L.activation(L.conv(s, self.conv_reduce), ACT_RELU)
         s = L.activation(L.conv(s, self.conv_expand), ACT_HSIGMOID)

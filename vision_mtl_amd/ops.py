@@ -52,6 +52,18 @@ def _k(name, _flop=None, _xflop=None, **kw):
     lib().callk(name, stream=_stream(), **kw)
 
 
+_STAMPS = None  # bench.py (VMTL_STAMPS=1) sets this to a list to collect a two-stream timeline
+
+
+def stamp(tag):
+    """Tuning aid: device wall-clock probe on the current stream (no-op unless _STAMPS is a list)."""
+    if _STAMPS is None:
+        return
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    lib().callk("vmtl_timestamp", out=t, stream=_stream())
+    _STAMPS.append((tag, t))
+
+
 def _slot(p):
     """Gradient slot of a parameter inside a dp.FlatArena (None when no arena is attached).  When a
     slot exists the backward kernels write the parameter gradient straight into it and autograd is
@@ -297,6 +309,7 @@ class _Conv2d(torch.autograd.Function):
         KK = KH * KW
         _, Ho, Wo, ldy = dy.shape
         dx = dw = db = None
+        stamp(f"main conv M={B * Ho * Wo} N={Cout} K={KK * Cin}")
         fork = side.mark()  # parameter gradients branch off here, before the data gradient
         if ctx.needs_input_grad[0]:
             if stride != 1:
@@ -309,6 +322,7 @@ class _Conv2d(torch.autograd.Function):
                 slabs, ns = _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Cout, KH, KW, stride, pad,
                                    2.0 * B * Ho * Wo * Cout * KK * Cin)
                 dw = unpack(slabs, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns)
+                stamp(f"side conv M={B * Ho * Wo} N={Cout} K={KK * Cin}")
             if ctx.slots[0] is not None:
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
@@ -376,6 +390,7 @@ class _Up2Conv(torch.autograd.Function):
         Cout, Cin = weight.shape[0], weight.shape[1]
         H, W, ldy = 2 * H2, 2 * W2, dy.shape[3]
         dxl = dskip = dw = None
+        stamp(f"main up2 M={B * H * W} N={Cout} Cin={Cin}")
         fork = side.mark()
         if ctx.needs_input_grad[0]:  # 4x4 / stride 2 / pad 1 convolution over dY with pre-summed taps
             wd = _empty((C0, 16 * ldy), xl)
@@ -400,6 +415,7 @@ class _Up2Conv(torch.autograd.Function):
                     slabs, ns = _wgrad(skip, dy, B, H, W, C1s, H, W, ldy, Cout, 3, 3, 1, 1,
                                        2.0 * B * H * W * Cout * 9 * C1)
                     unpack(slabs, None, 1, Cout, 9, C1, C1s, 0, Cin * 9, 1, 9, out=dw.view(-1)[C0 * 9:], nslabs=ns)
+                stamp(f"side up2 M={B * H * W} N={Cout} Cin={Cin}")
             if ctx.slot is not None:
                 dw = None
         return dxl, dskip, dw, None, None
@@ -497,6 +513,7 @@ class _DwConv(torch.autograd.Function):
         C, _, K, _ = weight.shape
         _, Ho, Wo, _ = dy.shape
         dx = dw = None
+        stamp(f"main dw M={B * Ho * Wo} C={C}")
         fork = side.mark()
         if ctx.needs_input_grad[0]:
             dx = _empty(x.shape, x)
@@ -508,6 +525,7 @@ class _DwConv(torch.autograd.Function):
                 dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
                 _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho,
                    Wo=Wo, K=K, stride=stride, pad=pad)
+                stamp(f"side dw M={B * Ho * Wo} C={C}")
             if ctx.slot is not None:
                 dw = None
         return dx, dw, None, None
@@ -737,6 +755,90 @@ def channel_scale(x, s):
 
 
 # ----------------------------------------------------------------------------- cross-stitch (diagonal scale)
+class _SqueezeExcite(torch.autograd.Function):
+    """y = x * act2(W_e act1(W_r mean_hw(x) + b_r) + b_e) - timm SqueezeExcite (ReLU / hard-sigmoid in
+    MobileNetV3), the gate of the `basic` encoder's inverted-residual blocks - as four launches: per-image
+    partial sums over HW, two batch-sized GEMMs (vmtl_fc_fwd: the first one finishes the mean while it loads
+    its operand), one scale pass.  Backward: partial sums of dy*x, two GEMMs with the activation backward
+    applied on load, one pass dx = dy*g + dmean/HW; the four parameter gradients come from two small
+    launches in the torch layout (side stream when they go to arena slots).  Weights are the torch
+    (R, C, 1, 1) / (C, R, 1, 1) conv parameters."""
+
+    @staticmethod
+    def forward(ctx, x, wr, br, we, be, act1, act2):
+        x, wr, we = _req(x, "x"), _req(wr, "reduce weight"), _req(we, "expand weight")
+        B, H, W, Cs = x.shape
+        HW = H * W
+        R, C = wr.shape[0], wr.shape[1]
+        if ceil4(C) != Cs or tuple(we.shape[:2]) != (C, R) or br is None or be is None:
+            raise ValueError("squeeze_excite: weights must be (R, C, 1, 1) / (C, R, 1, 1) with biases, matching x")
+        if B > lib().raw("vmtl_fc_max_rows")():
+            raise ValueError("squeeze_excite: batch too large for the batch-sized GEMM kernels")
+        Rs = ceil4(R)
+        S = lib().raw("vmtl_hw_reduce_parts")(B, HW, Cs)
+        parts = _empty((S, B, Cs), x)
+        _k("vmtl_hw_reduce", x=x, y=None, part=parts, B=B, HW=HW, Cs=Cs)
+        z1, h = _empty((B, Rs), x), _empty((B, Rs), x)
+        _k("vmtl_fc_fwd", a=parts, a_parts=S, a_part_stride=B * Cs, a_scale=1.0 / HW, a_z=None, a_act=0, w=wr, bias=br,
+           z=z1, y=h, M=B, K=C, N=R, lda=Cs, ldw=C, ldy=Rs, act=act1)
+        z2, g = _empty((B, Cs), x), _empty((B, Cs), x)
+        _k("vmtl_fc_fwd", a=h, a_parts=1, a_part_stride=0, a_scale=1.0, a_z=None, a_act=0, w=we, bias=be, z=z2, y=g,
+           M=B, K=R, N=C, lda=Rs, ldw=R, ldy=Cs, act=act2)
+        y = _empty(x.shape, x)
+        _k("vmtl_channel_scale_add", x=x, s=g, t=None, t_scale=0.0, y=y, B=B, HW=HW, Cs=Cs)
+        ctx.save_for_backward(x, parts, z1, h, z2, g, wr, we)
+        ctx.acts = (act1, act2)
+        ctx.slots = (_slot(wr), _slot(br), _slot(we), _slot(be))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, parts, z1, h, z2, g, wr, we = ctx.saved_tensors
+        act1, act2 = ctx.acts
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        HW = H * W
+        R, C = wr.shape[0], wr.shape[1]
+        Rs, S = ceil4(R), parts.shape[0]
+        # dg[b][c] = sum_hw dy*x, left as per-slice partial sums for the GEMM to finish
+        dparts = _empty((S, B, Cs), x)
+        _k("vmtl_hw_reduce", x=dy, y=x, part=dparts, B=B, HW=HW, Cs=Cs)
+        weT = packs.get(we, "dgrad", (1, R, 1, C, Cs, 0, 1, 1, R, 1))   # [R][Cs]
+        dh = _empty((B, Rs), x)
+        _k("vmtl_fc_fwd", a=dparts, a_parts=S, a_part_stride=B * Cs, a_scale=1.0, a_z=z2, a_act=act2, w=weT, bias=None,
+           z=None, y=dh, M=B, K=C, N=R, lda=Cs, ldw=Cs, ldy=Rs, act=0)
+        fork = side.mark()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wrT = packs.get(wr, "dgrad", (1, C, 1, R, Rs, 0, 1, 1, C, 1))  # [C][Rs]
+            dmean = _empty((B, Cs), x)
+            _k("vmtl_fc_fwd", a=dh, a_parts=1, a_part_stride=0, a_scale=1.0, a_z=z1, a_act=act1, w=wrT, bias=None,
+               z=None, y=dmean, M=B, K=R, N=C, lda=Rs, ldw=Rs, ldy=Cs, act=0)
+            dx = _empty(x.shape, x)
+            _k("vmtl_channel_scale_add", x=dy, s=g, t=dmean, t_scale=1.0 / HW, y=dx, B=B, HW=HW, Cs=Cs)
+        slots = ctx.slots
+        all_slots = all(s is not None for s in slots)
+        with side.branch(all_slots, B, fork, dparts, dh, parts, z1, h, z2):
+            dwr = _empty(wr.shape, x) if slots[0] is None else slots[0]
+            dbr = _empty((R,), x) if slots[1] is None else slots[1]
+            dwe = _empty(we.shape, x) if slots[2] is None else slots[2]
+            dbe = _empty((C,), x) if slots[3] is None else slots[3]
+            _k("vmtl_fc_wgrad", x=h, x_parts=1, x_part_stride=0, x_scale=1.0, dyo=dparts, dy_parts=S,
+               dy_part_stride=B * Cs, zo=z2, dw=dwe, db=dbe, M=B, K=R, N=C, lda=Rs, ldn=Cs, act=act2)
+            _k("vmtl_fc_wgrad", x=parts, x_parts=S, x_part_stride=B * Cs, x_scale=1.0 / HW, dyo=dh, dy_parts=1,
+               dy_part_stride=0, zo=z1, dw=dwr, db=dbr, M=B, K=C, N=R, lda=Cs, ldn=Rs, act=act1)
+        ret = [None if sl is not None else t for t, sl in zip((dwr, dbr, dwe, dbe), slots)]
+        return dx, ret[0], ret[1], ret[2], ret[3], None, None
+
+
+def squeeze_excite(x, w_reduce, b_reduce, w_expand, b_expand, act1=ACT_RELU, act2=ACT_HSIGMOID):
+    return _SqueezeExcite.apply(x, w_reduce, b_reduce, w_expand, b_expand, act1, act2)
+
+
+def squeeze_excite_max_batch() -> int:
+    return lib().raw("vmtl_fc_max_rows")()
+
+
 class _Stitch(torch.autograd.Function):
     """y = w[a, a, (c)] * x for task a; `weights` is the full (T,T[,C]) parameter
     (reference models/cross_stitch_model.py:21-37).  Off-diagonal entries get zero gradient."""
@@ -887,6 +989,7 @@ class _DualHead(torch.autograd.Function):
         _k("vmtl_nchw_to_nhwc", x=ga, y=dyf, B=B, C=Ca, HW=H * W, Cs=ldy, Cw=Ca)
         _k("vmtl_nchw_to_nhwc", x=gb, y=dyf[Ca:], B=B, C=Cb, HW=H * W, Cs=ldy, Cw=ldy - Ca)  # also zeroes pad lanes
         dx = None
+        fork = side.mark()
         if ctx.needs_input_grad[0]:
             # one tap-flipped, transposed operand [ci][tap'][co]: head a fills co < Ca and zeroes the rest of
             # every ldy-wide group, head b then fills co in [Ca, Ca+Cb)
@@ -895,17 +998,19 @@ class _DualHead(torch.autograd.Function):
                sc=Cin * KK, flip=1)
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, H, W, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=N)
-        slabs, ns = _wgrad(x, dy, B, H, W, Cs, H, W, ldy, N, KH, KW, 1, pad, 2.0 * B * H * W * N * KK * Cin)
-        stride = N * KK * Cs
-        dwa = unpack(slabs, wa.shape, 1, Ca, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns,
-                     slab_stride=stride)
-        dwb = unpack(slabs.view(-1)[Ca * KK * Cs:], wb.shape, 1, Cb, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[2],
-                     nslabs=ns, slab_stride=stride)
-        db = _colsum(dy, None, B * H * W, N, ldy)
-        dba = _empty((Ca,), x) if ctx.slots[1] is None else ctx.slots[1]
-        dbb = _empty((Cb,), x) if ctx.slots[3] is None else ctx.slots[3]
-        _copy_vec(db, dba, Ca)
-        _copy_vec(db[Ca:], dbb, Cb)
+        with side.branch(all(s is not None for s in ctx.slots), B * H * W, fork, x, dy):
+            slabs, ns = _wgrad(x, dy, B, H, W, Cs, H, W, ldy, N, KH, KW, 1, pad, 2.0 * B * H * W * N * KK * Cin)
+            stride = N * KK * Cs
+            dwa = unpack(slabs, wa.shape, 1, Ca, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns,
+                         slab_stride=stride)
+            dwb = unpack(slabs.view(-1)[Ca * KK * Cs:], wb.shape, 1, Cb, KK, Cin, Cs, 0, Cin * KK, 1, KK,
+                         out=ctx.slots[2], nslabs=ns, slab_stride=stride)
+            db = _colsum(dy, None, B * H * W, N, ldy)
+            dba = _empty((Ca,), x) if ctx.slots[1] is None else ctx.slots[1]
+            dbb = _empty((Cb,), x) if ctx.slots[3] is None else ctx.slots[3]
+            _copy_vec(db, dba, Ca)
+            _copy_vec(db[Ca:], dbb, Cb)
+            stamp("side head")
         none_if = lambda g, slot: None if slot is not None else g
         return (dx, none_if(dwa, ctx.slots[0]), none_if(dba, ctx.slots[1]), none_if(dwb, ctx.slots[2]),
                 none_if(dbb, ctx.slots[3]), None)
