@@ -62,19 +62,40 @@ struct ConvP {
 // lane dots its A fragment (already in registers) with the tail weight rows on the VALU.  With 33 / 20 /
 // 67 output channels this keeps the MFMA tiles at 32 / 16 / 64 useful columns instead of padding to
 // 48 / 32 / 80 (the VALU pipe is otherwise idle next to the matrix pipe).  Needs WAVES_N == 1.
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false, int NT = 0>
+//
+// NS >= 2: the staging tiles are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass) into NS buffers.  One wave-instruction writes 8 consecutive 128-byte rows lane-linearly,
+// so the XOR swizzle moves to the SOURCE address: the lane that lands on (row, slot) fetches k-quad
+// slot ^ (row & 7) (see k4 below).  Out-of-image taps / tile edges read a 16-byte zero page instead of
+// being zero-filled in registers.  Up to NS-1 tiles are in flight across the (raw) barrier.
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false, int NT = 0, int NS = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = WAVES_M * TM * 16;
   constexpr int BNM = WAVES_N * TN * 16;  // columns covered by MFMA tiles
   constexpr int BN = BNM + NT;            // + tail columns
   constexpr int RA = (BM + 31) / 32;      // A rows per loader thread
   constexpr int RB = (BN + 31) / 32;      // B rows per loader thread
+  constexpr int NBUF = NS >= 2 ? NS : 2;
+  constexpr int BNR = NS >= 2 ? RB * 32 : BN;  // LDS rows of one B stage (LDS-DMA writes whole 8-row groups)
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   static_assert(NT == 0 || WAVES_N == 1, "tail columns need all waves to span the full tile width");
+  static_assert(NS == 0 || (NS >= 2 && NS <= 4 && BM % 32 == 0), "LDS-DMA staging: 2..4 buffers, whole 32-row passes");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                 // [2][BM][LDT]
-  float* Bs = smem + 2 * BM * LDT;  // [2][BN][LDT]
+  float* As = smem;                    // [NBUF][BM][LDT]
+  float* Bs = smem + NBUF * BM * LDT;  // [NBUF][BNR][LDT]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,8 +115,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const float* wp = p.wp + (UP2 ? (size_t)phase * p.Nw * p.Ktot : 0);
 
   // ---- per-thread loader geometry ----
-  const int k4 = tid & 7;   // float4 column inside the BK chunk
   const int r0 = tid >> 3;  // 0..31
+  // float4 column inside the BK chunk.  Register staging: the thread picks the LDS slot when it stores.
+  // LDS-DMA: lane l of a wave lands on row (l>>3) of its 8-row group, slot (l&7) - it must FETCH the
+  // k-quad whose swizzled home that slot is: (l&7) ^ (row&7), row&7 == (tid>>3)&7.
+  const int k4 = NS >= 2 ? ((tid & 7) ^ (r0 & 7)) : (tid & 7);
   int pixbase[RA], hb[RA], wb[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   };
   auto store_tile = [&](int buf) {
     float* a = As + buf * BM * LDT;
-    float* b = Bs + buf * BN * LDT;
+    float* b = Bs + buf * BNR * LDT;
     const int ks = (k4 ^ (r0 & 7)) * 4;  // (r0 + 32 i) & 7 == r0 & 7
 #pragma unroll
     for (int i = 0; i < RA; ++i)
@@ -197,17 +221,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     ci += k_begin * BK;
     normalize();
   }
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) load_tile();  // global loads stay in flight under the MFMAs
+  // one BK chunk of MFMAs (+ VALU tail columns) on staging buffer `cur`
+  auto compute = [&](int cur) {
     // fragment rows are (tile base + l15) with tile bases multiples of 16: row & 7 == l15 & 7
     const float* a = As + cur * BM * LDT + (wm * TM * 16 + l15) * LDT;
-    const float* b = Bs + cur * BN * LDT + (wn * TN * 16 + l15) * LDT;
+    const float* b = Bs + cur * BNR * LDT + (wn * TN * 16 + l15) * LDT;
 #pragma unroll
     for (int kg = 0; kg < BK / 16; ++kg) {
       const int so = ((kg * 4 + lq) ^ (l15 & 7)) * 4;
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         // tail weight rows BNM + t (wave-uniform row, per-quarter k slot): 4 distinct LDS addresses
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const f32x4 ft = *reinterpret_cast<const f32x4*>(Bs + cur * BN * LDT + (BNM + t) * LDT +
+          const f32x4 ft = *reinterpret_cast<const f32x4*>(Bs + cur * BNR * LDT + (BNM + t) * LDT +
                                                            (((kg * 4 + lq) ^ ((BNM + t) & 7)) * 4));
 #pragma unroll
           for (int i = 0; i < TM; ++i)
@@ -235,9 +253,68 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
       }
     }
-    if (more) store_tile(cur ^ 1);
+  };
+
+  if constexpr (NS >= 2) {
+    constexpr int G = RA + RB;  // LDS-DMA instructions per wave and stage
+    auto issue = [&](int buf) {
+      const bool kok = kk < p.Ktot;
+      float* ad = As + (buf * BM + wv * 8) * LDT;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const float* src = g_zero_page;
+        if (!UP2 || seg == 0) {
+          const int h = hb[i] + dh, w = wb[i] + dw;
+          if (kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+            src = p.x + (size_t)(pixbase[i] + h * p.W + w) * p.Cs + ci;
+        } else {
+          const int h = 2 * hb[i] + 1 - pa + dh, w = 2 * wb[i] + 1 - pb + dw;
+          if (kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W))
+            src = p.x2 + ((size_t)4 * pixbase[i] + (size_t)h * (2 * p.W) + w) * p.C2s + ci;
+        }
+        glds16(src, ad + i * 32 * LDT);
+      }
+      float* bd = Bs + (buf * BNR + wv * 8) * LDT;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        const float* src = g_zero_page;
+        if (kok && n < p.Nw && r0 + 32 * i < BN) src = wp + (size_t)n * p.Ktot + kk;
+        glds16(src, bd + i * 32 * LDT);
+      }
+      kk += BK;
+      ci += BK;
+      normalize();
+    };
+    int issued = 0;
+    for (; issued < NS - 1 && issued < nk; ++issued) issue(issued);
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt must have landed; up to NS-2 younger stages may stay in flight across the barrier
+      const int pending = issued - kt - 1;
+      if (NS >= 4 && pending >= 2) wait_vmcnt<2 * G>();
+      else if (NS >= 3 && pending >= 1) wait_vmcnt<G>();
+      else wait_vmcnt<0>();
+      asm volatile("s_barrier" ::: "memory");  // raw: a __syncthreads() here would drain the DMA queue
+      if (issued < nk) {  // refill the buffer everybody finished reading before this barrier
+        issue(issued % NS);
+        ++issued;
+      }
+      compute(kt % NS);
+    }
+    __syncthreads();  // the epilogue reuses the staging memory
+  } else {
+    load_tile();
+    store_tile(0);
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) load_tile();  // global loads stay in flight under the MFMAs
+      compute(cur);
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // ---- epilogue: bias + activation, zero the pad channels, store ----
@@ -633,20 +710,46 @@ extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
   return kTiles[conv_pick_tile(B * Ho * Wo, ldy)].bm;
 }
 
+template <int TM, int TN, int WMV, int WNV, bool UP2, int NT, int NS>
+static int launch_conv_ns(ConvP& p, hipStream_t st);
+
+// LDS-DMA staging depth: 0 = register staging.  VMTL_GLDS overrides (tuning aid).
+static int conv_glds_stages() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VMTL_GLDS");
+    v = e ? atoi(e) : 0;
+    if (v != 0 && v != 2 && v != 3) v = 0;
+  }
+  return v;
+}
+
 template <int TM, int TN, int WMV, int WNV, bool UP2 = false, int NT = 0>
 static int launch_conv(ConvP& p, hipStream_t st) {
+  if constexpr (!UP2 && (WMV * TM) % 2 == 0) {
+    const int ns = conv_glds_stages();
+    if (ns == 2) return launch_conv_ns<TM, TN, WMV, WNV, UP2, NT, 2>(p, st);
+    if (ns == 3) return launch_conv_ns<TM, TN, WMV, WNV, UP2, NT, 3>(p, st);
+  }
+  return launch_conv_ns<TM, TN, WMV, WNV, UP2, NT, 0>(p, st);
+}
+
+template <int TM, int TN, int WMV, int WNV, bool UP2, int NT, int NS>
+static int launch_conv_ns(ConvP& p, hipStream_t st) {
   constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16 + NT;
   p.tiles_m = cdiv(p.M, BM) * (UP2 ? 4 : 1);
   p.tiles_n = cdiv(p.shuffle ? p.Nw : p.ldy, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+  constexpr int NBUF = NS >= 2 ? NS : 2;
+  constexpr int BNR = NS >= 2 ? (BN + 31) / 32 * 32 : BN;
+  const size_t lds = (size_t)NBUF * (BM + BNR) * LDT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT, NS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT>), dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1),
-                     dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT, NS>),
+                     dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
 

@@ -25,9 +25,12 @@ struct FcP {
   int M, K, N, lda, ldw, ldy, act;
 };
 
+#define FC_WAVES 8   // waves per workgroup, all splitting K
+#define FC_UNROLL 4  // K chunks whose loads are issued together (the loop is load-latency bound)
+
 template <int MT>
-__global__ __launch_bounds__(256) void fc_kernel(FcP p) {
-  __shared__ f32x4 red[4][MT][64];
+__global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(FcP p) {
+  __shared__ f32x4 red[FC_WAVES][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.x * 16;
@@ -37,54 +40,68 @@ __global__ __launch_bounds__(256) void fc_kernel(FcP p) {
   for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nchunks = (p.K + 15) >> 4;
   const bool wvec = (p.ldw & 3) == 0;
-  for (int c = wv; c < nchunks; c += 4) {
-    const int k4 = c * 16 + lq * 4;
-    f32x4 fb = {0.f, 0.f, 0.f, 0.f};
-    if (n < p.N && k4 < p.K) {
-      const float* wp = p.w + (size_t)n * p.ldw + k4;
-      if (wvec && k4 + 3 < p.K) {
-        fb = *reinterpret_cast<const f32x4*>(wp);
-      } else {
+  for (int c0 = wv; c0 < nchunks; c0 += FC_WAVES * FC_UNROLL) {
+    f32x4 fb[FC_UNROLL], fa[FC_UNROLL][MT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k4 + e < p.K) fb[e] = wp[e];
-      }
-    }
+    for (int u = 0; u < FC_UNROLL; ++u) {
+      const int c = c0 + u * FC_WAVES;
+      const int k4 = c * 16 + lq * 4;
+      fb[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (c < nchunks && n < p.N && k4 < p.K) {
+        const float* wp = p.w + (size_t)n * p.ldw + k4;
+        if (wvec && k4 + 3 < p.K) {
+          fb[u] = *reinterpret_cast<const f32x4*>(wp);
+        } else {
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int m = t * 16 + l15;
-      f32x4 fa = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && k4 < p.lda) {
-        const float* ap = p.a + (size_t)m * p.lda + k4;
-        fa = *reinterpret_cast<const f32x4*>(ap);
-        for (int s = 1; s < p.a_parts; ++s) fa += *reinterpret_cast<const f32x4*>(ap + s * p.a_part_stride);
-        fa *= p.a_scale;
-        if (p.a_z != nullptr) {
-          const f32x4 zv = *reinterpret_cast<const f32x4*>(p.a_z + (size_t)m * p.lda + k4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fa[e] *= act_grad(zv[e], p.a_act);
+          for (int e = 0; e < 4; ++e)
+            if (k4 + e < p.K) fb[u][e] = wp[e];
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acc[t], 0, 0, 0);
+      for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + l15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < nchunks && m < p.M && k4 < p.lda) {
+          const float* ap = p.a + (size_t)m * p.lda + k4;
+          v = *reinterpret_cast<const f32x4*>(ap);
+          for (int s = 1; s < p.a_parts; ++s) v += *reinterpret_cast<const f32x4*>(ap + s * p.a_part_stride);
+          v *= p.a_scale;
+          if (p.a_z != nullptr) {
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(p.a_z + (size_t)m * p.lda + k4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(zv[e], p.a_act);
+          }
+        }
+        fa[u][t] = v;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < FC_UNROLL; ++u)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][t][e], fb[u][e], acc[t], 0, 0, 0);
   }
 #pragma unroll
   for (int t = 0; t < MT; ++t) red[wv][t][lane] = acc[t];
   __syncthreads();
-  // C layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg.  Thread (ln, rg) finishes one element per tile.
-  const int ln = tid & 63, rg = tid >> 6;
+  // C layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg.  Thread (ln, rg) finishes element rg of
+  // lane ln's accumulator, tiles rt, rt + 2, ... (8 waves -> 2 tiles in flight)
+  if (tid >= 512) return;
+  const int ln = tid & 63, rg = (tid >> 6) & 3, rt = tid >> 8;
   const int col = ln & 15, row = 4 * (ln >> 4) + rg;
   const int nn = n0 + col;
   if (nn >= p.ldy) return;
   const float bv = (p.bias != nullptr && nn < p.N) ? p.bias[nn] : 0.f;
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
+  for (int t = rt; t < MT; t += 2) {
     const int m = t * 16 + row;
     if (m >= p.M) continue;
     const float* r0 = reinterpret_cast<const float*>(&red[0][t][ln]) + rg;
     constexpr int WS = MT * 64 * 4;  // floats between the per-wave copies
-    float v = r0[0] + r0[WS] + r0[2 * WS] + r0[3 * WS] + bv;
+    float v = bv;
+#pragma unroll
+    for (int w = 0; w < FC_WAVES; ++w) v += r0[w * WS];
     if (nn >= p.N) v = 0.f;
     if (p.z != nullptr) p.z[(size_t)m * p.ldy + nn] = v;
     p.y[(size_t)m * p.ldy + nn] = nn < p.N ? act_fwd(v, p.act) : 0.f;
@@ -103,10 +120,10 @@ extern "C" int vmtl_fc_fwd(const float* a, int a_parts, long long a_part_stride,
   const dim3 grid(cdiv(ldy, 16));
   hipStream_t st = (hipStream_t)stream;
   switch (cdiv(M, 16)) {
-    case 1: hipLaunchKernelGGL(fc_kernel<1>, grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL(fc_kernel<2>, grid, dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL(fc_kernel<3>, grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL(fc_kernel<4>, grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL(fc_kernel<1>, grid, dim3(FC_WAVES * 64), 0, st, p); break;
+    case 2: hipLaunchKernelGGL(fc_kernel<2>, grid, dim3(FC_WAVES * 64), 0, st, p); break;
+    case 3: hipLaunchKernelGGL(fc_kernel<3>, grid, dim3(FC_WAVES * 64), 0, st, p); break;
+    default: hipLaunchKernelGGL(fc_kernel<4>, grid, dim3(FC_WAVES * 64), 0, st, p); break;
   }
   return vmtl_check_launch();
 }
@@ -144,13 +161,25 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgP p) {
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int m = 0; m < p.M; ++m) {
-      const size_t off = (size_t)m * p.lda + k;
-      float xv = p.x[off];
-      for (int s = 1; s < p.x_parts; ++s) xv += p.x[off + s * p.x_part_stride];
-      xv *= p.x_scale;
+    for (int mb = 0; mb < p.M; mb += 8) {  // 8 independent loads in flight per thread
+      float xv[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += dz[m][i] * xv;
+      for (int u = 0; u < 8; ++u) {
+        xv[u] = 0.f;
+        if (mb + u < p.M) {
+          const size_t off = (size_t)(mb + u) * p.lda + k;
+          xv[u] = p.x[off];
+          for (int s = 1; s < p.x_parts; ++s) xv[u] += p.x[off + s * p.x_part_stride];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (mb + u < p.M) {
+          const float x1 = xv[u] * p.x_scale;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += dz[mb + u][i] * x1;
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -191,11 +220,31 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict_
   if (rg < RP && q < CQ) {
     const float* xb = x + (size_t)b * HW * Cs + (size_t)q * 4;
     const float* yb = y != nullptr ? y + (size_t)b * HW * Cs + (size_t)q * 4 : nullptr;
-    for (int r = r_begin + rg; r < r_end; r += RP) {
+    // 4 rows per trip: the loads are independent, the chain of adds is what serialises a plain loop
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    int r = r_begin + rg;
+    for (; r + 3 * RP < r_end; r += 4 * RP) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (size_t)r * Cs);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (size_t)(r + RP) * Cs);
+      f32x4 v2 = *reinterpret_cast<const f32x4*>(xb + (size_t)(r + 2 * RP) * Cs);
+      f32x4 v3 = *reinterpret_cast<const f32x4*>(xb + (size_t)(r + 3 * RP) * Cs);
+      if (yb != nullptr) {
+        v0 *= *reinterpret_cast<const f32x4*>(yb + (size_t)r * Cs);
+        v1 *= *reinterpret_cast<const f32x4*>(yb + (size_t)(r + RP) * Cs);
+        v2 *= *reinterpret_cast<const f32x4*>(yb + (size_t)(r + 2 * RP) * Cs);
+        v3 *= *reinterpret_cast<const f32x4*>(yb + (size_t)(r + 3 * RP) * Cs);
+      }
+      acc += v0;
+      a1 += v1;
+      a2 += v2;
+      a3 += v3;
+    }
+    for (; r < r_end; r += RP) {
       f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)r * Cs);
       if (yb != nullptr) v *= *reinterpret_cast<const f32x4*>(yb + (size_t)r * Cs);
       acc += v;
     }
+    acc += a1 + (a2 + a3);
   }
   red[tid] = acc;
   __syncthreads();
@@ -210,7 +259,8 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict_
 extern "C" int vmtl_hw_reduce_parts(int B, int HW, int Cs) {
   if (B <= 0 || HW <= 0 || Cs <= 0) return 0;
   const int cols = cdiv(Cs >> 2, 256);
-  int want = cdiv(1024, B * cols);        // ~4 workgroups per CU in total
+  // ~128 workgroups; every extra slice is an extra operand read in the GEMMs that consume the partials
+  int want = cdiv(128, B * cols);
   int cap = cdiv(HW, 32);                 // at least 32 rows per slice
   int S = want < cap ? want : cap;
   if (S < 1) S = 1;
