@@ -39,10 +39,18 @@ def _worker(rank, world, port, tmp):
     assert shard["img"].shape[0] == 2
     out = mtan_forward(_state(model), shard["img"], ["depth", "segm"], 2, training=False)
     F.cross_entropy(out["segm"], shard["mask"]).backward()  # accumulates into the arena views
+    local = arena.flat_grad.clone()
     scale = arena.all_reduce_mean()
     assert scale == 0.5
+    explicit = (arena.flat_grad * scale).clone()
+    # the hooked form: loss.backward() alone leaves the averaged gradient in the arena
+    arena.flat_grad.zero_()
+    out = mtan_forward(_state(model), shard["img"], ["depth", "segm"], 2, training=False)
+    arena.sync_loss(F.cross_entropy(out["segm"], shard["mask"])).backward()
+    assert not torch.equal(local, explicit)  # the ranks really saw different shards
+    assert torch.allclose(arena.flat_grad, explicit, rtol=0, atol=1e-7 * float(explicit.abs().max()))
     if rank == 0:
-        torch.save((arena.flat_grad * scale).clone(), tmp)
+        torch.save(explicit, tmp)
     dist.barrier()
     dist.destroy_process_group()
 

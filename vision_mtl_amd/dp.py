@@ -54,6 +54,19 @@ class FlatArena:
             return 1.0 / dist.get_world_size()
         return 1.0
 
+    def sync_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        """Return `loss` with the gradient averaging hooked onto its backward pass: when the autograd
+        engine finishes `loss.backward()` (engine callback, queued from the root of the graph) the side
+        stream is joined, the flat gradient is all-reduced once over RCCL and scaled by 1/world - so the
+        reference's `loss.backward(); optimizer.step()` (training_lit.py:85-87) needs no change
+        (last row).  MTLModule does this for the train stage when `dp_arena` is set."""
+        return _SyncGrads.apply(loss, self)
+
+    def _end_of_backward(self):
+        scale = self.all_reduce_mean()
+        if scale != 1.0:
+            self.flat_grad.mul_(scale)
+
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         """torch.optim.Adam semantics (reference training_lit.py:51,87) as ONE fused launch over the arena."""
         if self._adam is None:
@@ -65,6 +78,20 @@ class FlatArena:
         ops.adam_step(self.flat_param, self.flat_grad, st["m"], st["v"], st["step"], lr, betas, eps, weight_decay,
                       grad_scale)
         ops.packs.invalidate()  # parameters changed through raw pointers: packed operands are stale
+
+
+class _SyncGrads(torch.autograd.Function):
+    """Identity on the loss; its backward (the first node the engine runs) queues FlatArena._end_of_backward."""
+
+    @staticmethod
+    def forward(ctx, loss, arena):
+        ctx.arena = arena
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.autograd.Variable._execution_engine.queue_callback(ctx.arena._end_of_backward)
+        return g, None
 
 
 def init_distributed():

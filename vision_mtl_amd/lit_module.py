@@ -40,6 +40,7 @@ class MTLModule(nn.Module):
                         "jaccard_index": M.JaccardIndex(num_classes), "mae": M.MeanAbsoluteError()}
         self.automatic_optimization = False
         self.compute_metrics = True  # bench.py turns this off to time exactly fwd + losses + bwd
+        self.dp_arena = None  # a dp.FlatArena: training_step's loss then averages gradients over ranks at end of backward
 
     def forward(self, x: torch.Tensor) -> dict:
         return self.model(x)
@@ -52,6 +53,8 @@ class MTLModule(nn.Module):
         all_losses = self.calc_losses(gt_mask, gt_depth, out)
         all_metrics = self.calc_metrics(gt_mask, gt_depth, out)
         self.update_step_stats(stage, all_losses, all_metrics)
+        if stage == "train" and self.dp_arena is not None and torch.is_grad_enabled():
+            return self.dp_arena.sync_loss(all_losses["loss"])
         return all_losses["loss"]
 
     def update_step_stats(self, stage: str, all_losses: dict, all_metrics: dict) -> None:
