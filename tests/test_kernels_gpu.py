@@ -118,6 +118,25 @@ def test_conv2d_every_tile_config(dev, tile, monkeypatch):
     assert xd.grad[..., Cin:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("rows", [16, 32, 48, 64, 80, 144, 20, 36, 68])
+def test_conv2d_wgrad_every_row_config(dev, rows, monkeypatch):
+    """Each weight-gradient tile height (incl. the VALU tail-row ones) forced through the tuning override."""
+    ops = _ops()
+    monkeypatch.setenv("VMTL_FORCE_WG_ROWS", str(rows))
+    B, Cin, H, W, Cout = 2, 21, 19, 23, 70
+    g = torch.Generator().manual_seed(700 + rows)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    wd = w.to(dev).requires_grad_(True)
+    y = ops.conv2d(to_dev_nhwc(x, dev), wd, None, stride=1, pad=1)
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(wd.grad.cpu(), wr.grad, what=f"wgrad rows {rows}")
+
+
 @pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
 def test_conv_transpose2x2(dev, case):
     ops = _ops()

@@ -28,7 +28,9 @@ LAYERS = [("blk0.c1", 32, 8, 16, 1072, 540, 3), ("blk0.c2", 32, 8, 16, 540, 540,
           ("blk2.c1", 32, 32, 64, 294, 135, 3), ("blk2.c2", 32, 32, 64, 135, 135, 3),
           ("blk3.c1", 32, 64, 128, 151, 67, 3), ("blk3.c2", 32, 64, 128, 67, 67, 3),
           ("blk4.c1", 32, 128, 256, 67, 33, 3), ("blk4.c2", 32, 128, 256, 33, 33, 3),
-          ("head20", 32, 128, 256, 33, 20, 3)]
+          ("head20", 32, 128, 256, 33, 20, 3),
+          # same GEMM shapes as blk2.c2 / blk3.c2 without tap re-reads (1x1): isolates the im2col operand traffic
+          ("pw.blk2c2", 32, 32, 64, 1215, 135, 1), ("pw.blk3c2", 32, 64, 128, 603, 67, 1)]
 
 
 def timeit(fn):

@@ -507,10 +507,14 @@ struct WgradP {
 #define BP 32
 #define WG_BNK 128  // kk columns per workgroup (4 waves x 2 tiles x 16)
 
-template <int TM>  // co rows per workgroup = TM * 16; waves are laid out 1 x 4 along kk
+// co rows per workgroup = TM * 16 (+ NTR "tail" rows: the 33rd / 17-20th / 65-68th output channel is not
+// given an MFMA tile of its own - each lane multiplies its X fragment with the tail dY values on the VALU,
+// the same trick as the tail columns of conv_igemm_kernel); waves are laid out 1 x 4 along kk
+template <int TM, int NTR = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int TN = 2;
-  constexpr int BMC = TM * 16;
+  constexpr int BMM = TM * 16;    // rows covered by MFMA tiles
+  constexpr int BMC = BMM + NTR;  // + tail rows
   constexpr int LDY = BMC + 4;
   constexpr int LDX = WG_BNK + 4;
   constexpr int YQ = BMC / 4;                 // float4 per dY row
@@ -612,6 +616,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float tacc[NTR > 0 ? NTR : 1][TN];  // tail rows: this lane quarter's pixels only
+#pragma unroll
+  for (int t = 0; t < (NTR > 0 ? NTR : 1); ++t)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) tacc[t][j] = 0.f;
 
   if (p_begin < p_end) {
     load_tile(p_begin);
@@ -636,6 +645,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      if (NTR > 0) {  // dY[pixel 4s+lq][BMM .. BMM+3]: one 16-byte LDS read, broadcast within the quarter
+        const f32x4 ty = *reinterpret_cast<const f32x4*>(Ys + cur * BP * LDY + (4 * s + lq) * LDY + BMM);
+#pragma unroll
+        for (int t = 0; t < NTR; ++t)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) tacc[t][j] += ty[t] * fb[j];
+      }
     }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -654,6 +670,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         if (row < p.Nw && col < p.Ktot) slab[(size_t)row * p.Ktot + col] = acc[i][j][r];
       }
     }
+  if (NTR > 0) {
+#pragma unroll
+    for (int t = 0; t < NTR; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v = tacc[t][j];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int row = co0 + BMM + t;
+        const int col = kk0 + (wn * TN + j) * 16 + l15;
+        if (lq == 0 && row < p.Nw && col < p.Ktot) slab[(size_t)row * p.Ktot + col] = v;
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -919,11 +948,17 @@ static int wgrad_rows(int Nw) {
   // co rows per workgroup (TM*16).  Cost = padded rows / relative efficiency of that tile height:
   // a 16- or 32-row tile issues 3-4 LDS reads per 2-4 MFMAs and loses to a taller, slightly more
   // padded one (measured: Nw=270 as 17x16 rows ran at 42 TF, as 2x144 at ~90 TF).
-  static const int cands[] = {16, 32, 48, 64, 80, 144};
-  static const float eff[] = {0.35f, 0.55f, 0.72f, 0.82f, 0.88f, 1.0f};
+  // 20 / 36 / 68 = 16 / 32 / 64 MFMA rows + 4 tail rows on the VALU
+  static const int cands[] = {16, 32, 48, 64, 80, 144, 20, 36, 68};
+  static const float eff[] = {0.35f, 0.55f, 0.72f, 0.82f, 0.88f, 1.0f, 0.43f, 0.61f, 0.86f};
+  if (const char* f = getenv("VMTL_FORCE_WG_ROWS")) {  // tuning aid
+    const int v = atoi(f);
+    for (int i = 0; i < 9; ++i)
+      if (cands[i] == v) return v;
+  }
   int best = 16;
   float bc = -1.f;
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < 9; ++i) {
     const float cost = (float)((long long)cdiv(Nw, cands[i]) * cands[i]) / eff[i];
     if (bc < 0.f || cost < bc) {
       best = cands[i];
@@ -951,20 +986,20 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   return cdiv(M, chunk);
 }
 
-template <int TM>
+template <int TM, int NTR = 0>
 static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
-  constexpr int BMC = TM * 16;
+  constexpr int BMC = TM * 16 + NTR;
   const size_t lds = (size_t)2 * BP * ((BMC + 4) + (WG_BNK + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, NTR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   p.tiles_kk = cdiv(p.Ktot, WG_BNK);
   p.tiles_co = cdiv(p.Nw, BMC);
   p.splits = splits;
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, NTR>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
 
@@ -987,6 +1022,9 @@ extern "C" int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, 
     case 48: return launch_wgrad<3>(p, splits, st);
     case 64: return launch_wgrad<4>(p, splits, st);
     case 80: return launch_wgrad<5>(p, splits, st);
+    case 20: return launch_wgrad<1, 4>(p, splits, st);
+    case 36: return launch_wgrad<2, 4>(p, splits, st);
+    case 68: return launch_wgrad<4, 4>(p, splits, st);
     default: return launch_wgrad<9>(p, splits, st);
   }
 }
