@@ -280,6 +280,15 @@ def main():
                                "flop_per_launch": round(ig["flop"] / max(ig["launches"], 1)),
                                "executed_tflops": round(ig.get("xflop", ig["flop"]) / (ig["ms"] * 1e-3) / 1e12, 2),
                                "ms_per_step_in_kernel": round(ig["ms"], 3)}
+            # HBM bytes per launch from the hardware counters: cannot be collected inside this process, so the
+            # committed rocprofv3 --pmc summary of this same workload is quoted (profiles/)
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_hbm_traffic_pmc.json")
+            if (args.model, args.height, args.width, args.batch) == ("basic", 128, 256, 32) and os.path.exists(pmc):
+                with open(pmc) as f:
+                    k = json.load(f)["kernels"].get("conv_igemm_kernel")
+                if k:
+                    out["roofline"]["traffic"] = round(k["hbm_bytes_per_launch"])
+                    out["roofline"]["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
             wg = fam["vmtl_conv2d_wgrad"]
             if wg["ms"] > 0:
                 wach = wg["flop"] / (wg["ms"] * 1e-3) / 1e12
