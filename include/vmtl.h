@@ -133,15 +133,16 @@ int vmtl_channel_scale_bwd_s(const float* x, const float* dy, float* ds, int B, 
  * SqueezeExcite on a (B,1,1,C) map (encoder of models/basic_model.py:17-28).
  * vmtl_fc_fwd: z = bias + A W^T, y = act(z); A = a_scale * sum_{s<a_parts} a[s] (partial sums of a spatial
  *   reduction), optionally multiplied by act'(a_z) with activation a_act (data gradient with the activation
- *   backward fused: pass the transposed weight as w).  w is [N][ldw] with K contiguous; z may be NULL.
+ *   backward fused: pass the transposed weight as w).  w is [N][ldw] with K contiguous; z may be NULL;
+ *   a_out (may be NULL) receives the finished A operand [M][lda] (summed, scaled, unmasked).
  * vmtl_fc_wgrad: dw[n][k] = sum_m dz[m][n] x[m][k], db[n] = sum_m dz[m][n], dz = (sum of dy parts) * act'(zo);
  *   dw in the torch (N, K, 1, 1) layout.
  * vmtl_hw_reduce: part[s][b][c] = sum over HW slice s of x (* y if given); S = vmtl_hw_reduce_parts(B,HW,Cs).
  * vmtl_channel_scale_add: y = x * s[b][c] + t[b][c] * t_scale (t may be NULL). */
 int vmtl_fc_max_rows(void);
 int vmtl_fc_fwd(const float* a, int a_parts, long long a_part_stride, float a_scale, const float* a_z, int a_act,
-                const float* w, const float* bias, float* z, float* y, int M, int K, int N, int lda, int ldw, int ldy,
-                int act, void* stream);
+                float* a_out, const float* w, const float* bias, float* z, float* y, int M, int K, int N, int lda,
+                int ldw, int ldy, int act, void* stream);
 int vmtl_fc_wgrad(const float* x, int x_parts, long long x_part_stride, float x_scale, const float* dyo, int dy_parts,
                   long long dy_part_stride, const float* zo, float* dw, float* db, int M, int K, int N, int lda, int ldn,
                   int act, void* stream);

@@ -17,6 +17,7 @@ struct FcP {
   const float* a_z;   // nullable [M][lda]: pre-activations whose act_grad masks the A operand
   const float* w;     // [N][ldw], K contiguous
   const float* bias;  // nullable [N]
+  float* a_out;       // nullable [M][lda]: the finished A operand (parts summed and scaled, before the a_z mask)
   float* z;           // nullable [M][ldy] pre-activation output
   float* y;           // [M][ldy] = act(z); pad columns zero
   long long a_part_stride;
@@ -66,6 +67,9 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(FcP p) {
           v = *reinterpret_cast<const f32x4*>(ap);
           for (int s = 1; s < p.a_parts; ++s) v += *reinterpret_cast<const f32x4*>(ap + s * p.a_part_stride);
           v *= p.a_scale;
+          // every workgroup computes the same finished operand: workgroup (c mod grid) keeps chunk c
+          if (p.a_out != nullptr && (c % (int)gridDim.x) == (int)blockIdx.x)
+            *reinterpret_cast<f32x4*>(p.a_out + (size_t)m * p.lda + k4) = v;
           if (p.a_z != nullptr) {
             const f32x4 zv = *reinterpret_cast<const f32x4*>(p.a_z + (size_t)m * p.lda + k4);
 #pragma unroll
@@ -111,12 +115,12 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(FcP p) {
 extern "C" int vmtl_fc_max_rows() { return 64; }
 
 extern "C" int vmtl_fc_fwd(const float* a, int a_parts, long long a_part_stride, float a_scale, const float* a_z,
-                           int a_act, const float* w, const float* bias, float* z, float* y, int M, int K, int N,
-                           int lda, int ldw, int ldy, int act, void* stream) {
+                           int a_act, float* a_out, const float* w, const float* bias, float* z, float* y, int M,
+                           int K, int N, int lda, int ldw, int ldy, int act, void* stream) {
   if (!a || !w || !y || M <= 0 || M > 64 || K <= 0 || N <= 0 || (lda & 3) || lda < K || ldw < K || ldy < N ||
       a_parts < 1 || (a_parts > 1 && (a_part_stride & 3)))
     return VMTL_ERR_ARG;
-  FcP p{a, a_z, w, bias, z, y, a_part_stride, a_scale, a_parts, a_act, M, K, N, lda, ldw, ldy, act};
+  FcP p{a, a_z, w, bias, a_out, z, y, a_part_stride, a_scale, a_parts, a_act, M, K, N, lda, ldw, ldy, act};
   const dim3 grid(cdiv(ldy, 16));
   hipStream_t st = (hipStream_t)stream;
   switch (cdiv(M, 16)) {

@@ -787,53 +787,56 @@ class _SqueezeExcite(torch.autograd.Function):
         parts = _empty((S, B, Cs), x)
         _k("vmtl_hw_reduce", x=x, y=None, part=parts, B=B, HW=HW, Cs=Cs)
         z1, h = _empty((B, Rs), x), _empty((B, Rs), x)
-        _k("vmtl_fc_fwd", a=parts, a_parts=S, a_part_stride=B * Cs, a_scale=1.0 / HW, a_z=None, a_act=0, w=wr, bias=br,
-           z=z1, y=h, M=B, K=C, N=R, lda=Cs, ldw=C, ldy=Rs, act=act1)
+        pooled = _empty((B, Cs), x)  # finished mean (a_out): every [b][c < Cs] is written since Cs <= ceil16(C)
+        _k("vmtl_fc_fwd", a=parts, a_parts=S, a_part_stride=B * Cs, a_scale=1.0 / HW, a_z=None, a_act=0, a_out=pooled,
+           w=wr, bias=br, z=z1, y=h, M=B, K=C, N=R, lda=Cs, ldw=C, ldy=Rs, act=act1)
         z2, g = _empty((B, Cs), x), _empty((B, Cs), x)
-        _k("vmtl_fc_fwd", a=h, a_parts=1, a_part_stride=0, a_scale=1.0, a_z=None, a_act=0, w=we, bias=be, z=z2, y=g,
-           M=B, K=R, N=C, lda=Rs, ldw=R, ldy=Cs, act=act2)
+        _k("vmtl_fc_fwd", a=h, a_parts=1, a_part_stride=0, a_scale=1.0, a_z=None, a_act=0, a_out=None, w=we, bias=be,
+           z=z2, y=g, M=B, K=R, N=C, lda=Rs, ldw=R, ldy=Cs, act=act2)
         y = _empty(x.shape, x)
         _k("vmtl_channel_scale_add", x=x, s=g, t=None, t_scale=0.0, y=y, B=B, HW=HW, Cs=Cs)
-        ctx.save_for_backward(x, parts, z1, h, z2, g, wr, we)
+        ctx.save_for_backward(x, pooled, z1, h, z2, g, wr, we)
+        ctx.S = S
         ctx.acts = (act1, act2)
         ctx.slots = (_slot(wr), _slot(br), _slot(we), _slot(be))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, parts, z1, h, z2, g, wr, we = ctx.saved_tensors
+        x, pooled, z1, h, z2, g, wr, we = ctx.saved_tensors
         act1, act2 = ctx.acts
         dy = _req(dy, "dy")
         B, H, W, Cs = x.shape
         HW = H * W
         R, C = wr.shape[0], wr.shape[1]
-        Rs, S = ceil4(R), parts.shape[0]
+        Rs, S = ceil4(R), ctx.S
         # dg[b][c] = sum_hw dy*x, left as per-slice partial sums for the GEMM to finish
         dparts = _empty((S, B, Cs), x)
         _k("vmtl_hw_reduce", x=dy, y=x, part=dparts, B=B, HW=HW, Cs=Cs)
         weT = packs.get(we, "dgrad", (1, R, 1, C, Cs, 0, 1, 1, R, 1))   # [R][Cs]
         dh = _empty((B, Rs), x)
-        _k("vmtl_fc_fwd", a=dparts, a_parts=S, a_part_stride=B * Cs, a_scale=1.0, a_z=z2, a_act=act2, w=weT, bias=None,
-           z=None, y=dh, M=B, K=C, N=R, lda=Cs, ldw=Cs, ldy=Rs, act=0)
+        dg = _empty((B, Cs), x)  # finished sum_hw dy*x (a_out), for the weight gradient
+        _k("vmtl_fc_fwd", a=dparts, a_parts=S, a_part_stride=B * Cs, a_scale=1.0, a_z=z2, a_act=act2, a_out=dg, w=weT,
+           bias=None, z=None, y=dh, M=B, K=C, N=R, lda=Cs, ldw=Cs, ldy=Rs, act=0)
         fork = side.mark()
         dx = None
         if ctx.needs_input_grad[0]:
             wrT = packs.get(wr, "dgrad", (1, C, 1, R, Rs, 0, 1, 1, C, 1))  # [C][Rs]
             dmean = _empty((B, Cs), x)
-            _k("vmtl_fc_fwd", a=dh, a_parts=1, a_part_stride=0, a_scale=1.0, a_z=z1, a_act=act1, w=wrT, bias=None,
-               z=None, y=dmean, M=B, K=R, N=C, lda=Rs, ldw=Rs, ldy=Cs, act=0)
+            _k("vmtl_fc_fwd", a=dh, a_parts=1, a_part_stride=0, a_scale=1.0, a_z=z1, a_act=act1, a_out=None, w=wrT,
+               bias=None, z=None, y=dmean, M=B, K=R, N=C, lda=Rs, ldw=Rs, ldy=Cs, act=0)
             dx = _empty(x.shape, x)
             _k("vmtl_channel_scale_add", x=dy, s=g, t=dmean, t_scale=1.0 / HW, y=dx, B=B, HW=HW, Cs=Cs)
         slots = ctx.slots
         all_slots = all(s is not None for s in slots)
-        with side.branch(all_slots, B, fork, dparts, dh, parts, z1, h, z2):
+        with side.branch(all_slots, B, fork, dg, dh, pooled, z1, h, z2):
             dwr = _empty(wr.shape, x) if slots[0] is None else slots[0]
             dbr = _empty((R,), x) if slots[1] is None else slots[1]
             dwe = _empty(we.shape, x) if slots[2] is None else slots[2]
             dbe = _empty((C,), x) if slots[3] is None else slots[3]
-            _k("vmtl_fc_wgrad", x=h, x_parts=1, x_part_stride=0, x_scale=1.0, dyo=dparts, dy_parts=S,
-               dy_part_stride=B * Cs, zo=z2, dw=dwe, db=dbe, M=B, K=R, N=C, lda=Rs, ldn=Cs, act=act2)
-            _k("vmtl_fc_wgrad", x=parts, x_parts=S, x_part_stride=B * Cs, x_scale=1.0 / HW, dyo=dh, dy_parts=1,
+            _k("vmtl_fc_wgrad", x=h, x_parts=1, x_part_stride=0, x_scale=1.0, dyo=dg, dy_parts=1, dy_part_stride=0,
+               zo=z2, dw=dwe, db=dbe, M=B, K=R, N=C, lda=Rs, ldn=Cs, act=act2)
+            _k("vmtl_fc_wgrad", x=pooled, x_parts=1, x_part_stride=0, x_scale=1.0, dyo=dh, dy_parts=1,
                dy_part_stride=0, zo=z1, dw=dwr, db=dbr, M=B, K=C, N=R, lda=Cs, ldn=Rs, act=act1)
         ret = [None if sl is not None else t for t, sl in zip((dwr, dbr, dwe, dbe), slots)]
         return dx, ret[0], ret[1], ret[2], ret[3], None, None
