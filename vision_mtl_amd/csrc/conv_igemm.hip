@@ -161,29 +161,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   f32x4 ra[RA], rb[RB];
 
+  // Register staging goes through BUFFER loads: 32-bit byte offsets instead of 64-bit pointer arithmetic, and
+  // an out-of-image tap / tile edge is an out-of-range offset, which the hardware answers with zeros - no
+  // zero-fill moves, no divergent branch around the load (the narrow tiles were VALU-issue bound: 7 VALU
+  // instructions per MFMA, measured with SQ_INSTS_VALU / SQ_INSTS_MFMA).
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((unsigned)p.B * p.H * p.W * p.Cs * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(UP2 && p.x2 != nullptr ? p.x2 : p.x), 0, UP2 ? (int)(16u * p.B * p.H * p.W * p.C2s) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)((unsigned)p.Nw * p.Ktot * 4u), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
+
   auto load_tile = [&]() {
     const bool kok = kk < p.Ktot;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (!UP2 || seg == 0) {
         const int h = hb[i] + dh, w = wb[i] + dw;
-        if (kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(pixbase[i] + h * p.W + w) * p.Cs + ci);
+        const bool ok = kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        const unsigned off = ((unsigned)(pixbase[i] + h * p.W + w) * (unsigned)p.Cs + (unsigned)ci) * 4u;
+        ra[i] = bload(rs_x, ok ? off : OOB);
       } else {
         // full-res skip: output pixel (2*h2 + pa, 2*w2 + pb), tap offset dh-1 / dw-1; hb = h2 - 1 + pa
         const int h = 2 * hb[i] + 1 - pa + dh, w = 2 * wb[i] + 1 - pb + dw;
-        if (kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W))
-          v = *reinterpret_cast<const f32x4*>(p.x2 + ((size_t)4 * pixbase[i] + (size_t)h * (2 * p.W) + w) * p.C2s + ci);
+        const bool ok = kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W);
+        const unsigned off = ((unsigned)(4 * pixbase[i] + h * (2 * p.W) + w) * (unsigned)p.C2s + (unsigned)ci) * 4u;
+        ra[i] = bload(rs_x2, ok ? off : OOB);
       }
-      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int n = n0 + r0 + 32 * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kok && n < p.Nw && r0 + 32 * i < BN) v = *reinterpret_cast<const f32x4*>(wp + (size_t)n * p.Ktot + kk);
-      rb[i] = v;
+      const bool ok = kok && n < p.Nw && r0 + 32 * i < BN;
+      rb[i] = bload(rs_w, ok ? ((unsigned)n * (unsigned)p.Ktot + (unsigned)kk) * 4u : OOB);
     }
     // advance to the next BK chunk
     kk += BK;
@@ -768,6 +781,10 @@ static int launch_conv_ns(ConvP& p, hipStream_t st) {
   constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16 + NT;
   p.tiles_m = cdiv(p.M, BM) * (UP2 ? 4 : 1);
   p.tiles_n = cdiv(p.shuffle ? p.Nw : p.ldy, BN);
+  // buffer addressing: every operand is reached through a 32-bit byte offset
+  if ((long long)p.B * p.H * p.W * p.Cs * 4 >= (1ll << 32) || (long long)p.Nw * p.Ktot * 4 >= (1ll << 32) ||
+      (UP2 && (long long)16 * p.B * p.H * p.W * p.C2s >= (1ll << 32)))
+    return VMTL_ERR_UNSUPPORTED;
   constexpr int NBUF = NS >= 2 ? NS : 2;
   constexpr int BNR = NS >= 2 ? (BN + 31) / 32 * 32 : BN;
   const size_t lds = (size_t)NBUF * (BM + BNR) * LDT * sizeof(float);
