@@ -580,25 +580,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   }
 
   f32x4 ry[YIT], rx[XP];
+  // buffer loads: 32-bit offsets, out-of-range (slice end, image border, tile edge) reads return zeros
+  const __amdgpu_buffer_rsrc_t rs_dy =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * p.ldy * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((unsigned)p.B * p.H * p.W * p.Cs * 4u), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  };
   auto load_tile = [&](int pp) {
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
       const int idx = tid + it * 256;
       const int row = idx / YQ, q = idx - row * YQ;
       const int m = pp + row, co = co0 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < BP * YQ && m < p_end && co < p.ldy) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + co);
-      ry[it] = v;
+      const bool ok = idx < BP * YQ && m < p_end && co < p.ldy;
+      ry[it] = bload(rs_dy, ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u : OOB);
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int m = pp + xr + XROWS * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xok && m < p_end) {
-        const int h = xho[i] * p.stride + dh, w = xwo[i] * p.stride + dw;
-        if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)(xb[i] * p.H + h) * p.W + w) * p.Cs + ci);
-      }
+      const int h = xho[i] * p.stride + dh, w = xwo[i] * p.stride + dw;
+      const bool ok = xok && m < p_end && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+      const unsigned off = ((unsigned)((xb[i] * p.H + h) * p.W + w) * (unsigned)p.Cs + (unsigned)ci) * 4u;
+      f32x4 v = bload(rs_x, ok ? off : OOB);
       rx[i] = v;
       // advance this row by BP pixels
       xwo[i] += BP;
@@ -1013,6 +1019,8 @@ static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  if ((long long)p.M * p.ldy * 4 >= (1ll << 32) || (long long)p.B * p.H * p.W * p.Cs * 4 >= (1ll << 32))
+    return VMTL_ERR_UNSUPPORTED;  // buffer addressing: 32-bit byte offsets
   p.tiles_kk = cdiv(p.Ktot, WG_BNK);
   p.tiles_co = cdiv(p.Nw, BMC);
   p.splits = splits;
