@@ -21,6 +21,7 @@
 #define VMTL_ACT_HSIGMOID 3
 #define VMTL_ACT_SIGMOID 4
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -220,11 +220,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float tacc[TM][NT > 0 ? NT : 1];  // tail columns: per-lane partial dot products over this lane's k quads
+  // tail columns: per-lane partial dot products over this lane's k quads, kept as (even k, odd k) pairs so
+  // the multiply-adds are v_pk_fma_f32 on register pairs that already sit next to each other
+  f32x2 tacc[TM][NT > 0 ? NT : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int t = 0; t < (NT > 0 ? NT : 1); ++t) tacc[i][t] = 0.f;
+    for (int t = 0; t < (NT > 0 ? NT : 1); ++t) tacc[i][t] = (f32x2){0.f, 0.f};
 
   int nk = (p.Ktot + BK - 1) / BK;
   if (p.ksplit > 1) {  // this workgroup's K slice: skip ahead, then run ksteps_per_split chunks
@@ -260,9 +262,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         for (int t = 0; t < NT; ++t) {
           const f32x4 ft = *reinterpret_cast<const f32x4*>(Bs + cur * BNR * LDT + (BNM + t) * LDT +
                                                            (((kg * 4 + lq) ^ ((BNM + t) & 7)) * 4));
+          const f32x2 ft_lo = __builtin_shufflevector(ft, ft, 0, 1), ft_hi = __builtin_shufflevector(ft, ft, 2, 3);
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-            tacc[i][t] += fa[i][0] * ft[0] + fa[i][1] * ft[1] + fa[i][2] * ft[2] + fa[i][3] * ft[3];
+          for (int i = 0; i < TM; ++i) {
+            tacc[i][t] += __builtin_shufflevector(fa[i], fa[i], 0, 1) * ft_lo;
+            tacc[i][t] += __builtin_shufflevector(fa[i], fa[i], 2, 3) * ft_hi;
+          }
         }
       }
     }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        float v = tacc[i][t];
+        float v = tacc[i][t][0] + tacc[i][t][1];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         const int n = n0 + BNM + t;
