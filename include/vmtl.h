@@ -104,6 +104,13 @@ int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int 
 int vmtl_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, const float* mul, const float* res, float* y, long long M, int C,
                   int Cs, int act, void* stream);
+/* finalize + apply in one launch for training-mode BatchNorm whose statistics come as few per-block rows
+ * (nblk <= vmtl_bn_fuse_max_rows(); same arguments as vmtl_bn_stats with conv partials + vmtl_bn_apply) */
+int vmtl_bn_fuse_max_rows(void);
+int vmtl_bn_apply_fused(const float* x, const float* partial, int nblk, int rows_per_blk, float eps, float momentum,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, float* save_mean,
+                        float* save_invstd, const float* gamma, const float* beta, const float* mul, const float* res,
+                        float* y, long long M, int C, int Cs, int act, void* stream);
 int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, const float* mul, float* dmul, float* partial, float* sum_dz,
                 float* sum_dzx, float* dx, int M, int C, int Cs, int act, int training, void* stream);

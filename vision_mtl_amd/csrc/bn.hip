@@ -210,6 +210,88 @@ __global__ __launch_bounds__(RED_THREADS) void bn_apply_kernel(const float* __re
       });
 }
 
+// Training-mode BatchNorm with FEW statistics rows (small feature maps: the deep half of the MobileNetV3
+// encoder): finalize + apply in ONE launch.  Every thread merges the nblk (mean_b, M2_b) rows of its own
+// channel quad with Chan's formula in fp64 (nblk <= VMTL_BN_FUSE_MAX_ROWS float4 pairs out of L2) instead
+// of waiting for a separate one-workgroup-per-channel finalize launch; workgroup 0 also publishes
+// mean / invstd for the backward pass and updates the running buffers.
+#define VMTL_BN_FUSE_MAX_ROWS 64
+
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void bn_apply_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ partial, int nblk, int rows_per_blk, float eps, float momentum,
+    float* running_mean, float* running_var, long long* num_batches_tracked, float* save_mean, float* save_invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mul,
+    const float* __restrict__ res, float* __restrict__ y, int M, int C, int Cs) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
+  column_sweep(
+      M, Cs >> 2,
+      [&](int q) {
+        auto rows_of = [&](int b) { return max(0, min(rows_per_blk, M - b * rows_per_blk)); };
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < nblk; ++b) {
+          const f32x4 mb = *reinterpret_cast<const f32x4*>(partial + ((size_t)b * 2 + 0) * Cs + (size_t)q * 4);
+          const double nb = rows_of(b);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += nb * (double)mb[e];
+        }
+        double m2[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < nblk; ++b) {
+          const double nb = rows_of(b);
+          if (nb > 0.0) {
+            const f32x4 mb = *reinterpret_cast<const f32x4*>(partial + ((size_t)b * 2 + 0) * Cs + (size_t)q * 4);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(partial + ((size_t)b * 2 + 1) * Cs + (size_t)q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const double d = (double)mb[e] - s[e] / M;
+              m2[e] += (double)vb[e] + nb * d * d;
+            }
+          }
+        }
+        // the first row lane of workgroup 0 owns the channel's published statistics
+        const bool owner = blockIdx.x == 0 && (int)threadIdx.x == (q % RED_THREADS);  // row lane 0 of workgroup 0
+        BnCoef k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = q * 4 + e;
+          float sc = 0.f, sh = 0.f, v = 0.f, mean_f = 0.f, istd_f = 0.f;
+          if (c < C) {
+            const double mean = s[e] / M;
+            double var = m2[e] / M;
+            if (var < 0.0) var = 0.0;
+            mean_f = (float)mean;
+            istd_f = (float)(1.0 / sqrt(var + (double)eps));
+            v = 1.f;
+            sc = (gamma ? gamma[c] : 1.f) * istd_f;
+            sh = (beta ? beta[c] : 0.f) - mean_f * sc;
+            if (owner && running_mean != nullptr) {
+              const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+              running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+              running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+          }
+          if (owner) {
+            save_mean[c] = mean_f;
+            save_invstd[c] = istd_f;
+          }
+          k.sc[e] = sc;
+          k.sh[e] = sh;
+          k.valid[e] = v;
+        }
+        return k;
+      },
+      [&](int r, int q, const BnCoef& k) {
+        const size_t off = (size_t)r * Cs + (size_t)q * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = k.valid[e] != 0.f ? act_fwd(v[e] * k.sc[e] + k.sh[e], ACT) : 0.f;
+        if (mul != nullptr) o *= *reinterpret_cast<const f32x4*>(mul + off);
+        if (res != nullptr) o += *reinterpret_cast<const f32x4*>(res + off);
+        *reinterpret_cast<f32x4*>(y + off) = o;
+      });
+}
+
 #define VMTL_ACT_SWITCH(act, CALL)                   \
   switch (act) {                                     \
     case VMTL_ACT_NONE: CALL(VMTL_ACT_NONE); break;   \
@@ -229,6 +311,27 @@ extern "C" int vmtl_bn_apply(const float* x, const float* mean, const float* inv
 #define CALL(A)                                                                                                   \
   hipLaunchKernelGGL((bn_apply_kernel<A>), dim3(nb), dim3(RED_THREADS), 0, (hipStream_t)stream, x, mean, invstd, \
                      gamma, beta, mul, res, y, (int)M, C, Cs)
+  VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_bn_fuse_max_rows() { return VMTL_BN_FUSE_MAX_ROWS; }
+
+extern "C" int vmtl_bn_apply_fused(const float* x, const float* partial, int nblk, int rows_per_blk, float eps,
+                                   float momentum, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float* save_mean, float* save_invstd,
+                                   const float* gamma, const float* beta, const float* mul, const float* res, float* y,
+                                   long long M, int C, int Cs, int act, void* stream) {
+  if (!x || !y || !partial || !save_mean || !save_invstd || M <= 0 || M > 0x7fffffffLL || C <= 0 || C > Cs || (Cs & 3))
+    return VMTL_ERR_ARG;
+  if (nblk <= 0 || nblk > VMTL_BN_FUSE_MAX_ROWS || rows_per_blk <= 0 || (long long)nblk * rows_per_blk < M)
+    return VMTL_ERR_ARG;
+  const int nb = sweep_blocks(M, Cs);
+#define CALL(A)                                                                                                    \
+  hipLaunchKernelGGL((bn_apply_fused_kernel<A>), dim3(nb), dim3(RED_THREADS), 0, (hipStream_t)stream, x, partial, \
+                     nblk, rows_per_blk, eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, \
+                     save_invstd, gamma, beta, mul, res, y, (int)M, C, Cs)
   VMTL_ACT_SWITCH(act, CALL)
 #undef CALL
   return vmtl_check_launch();

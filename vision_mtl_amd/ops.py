@@ -544,6 +544,11 @@ def dwconv(x, weight, stride=1, pad=1):
 
 
 # ----------------------------------------------------------------------------- BatchNorm + act (+ gate, + residual)
+# statistics rows up to which BatchNorm finalize is folded into the apply launch (VMTL_BN_FUSE_ROWS overrides;
+# the library accepts at most vmtl_bn_fuse_max_rows())
+_BN_FUSE_ROWS = int(os.environ.get("VMTL_BN_FUSE_ROWS", "16"))  # measured: 16 rows neutral, 64 rows +0.5 ms/step (redundant fp64 merges)
+
+
 class _BNAct(torch.autograd.Function):
     """y = act(BN(x)) [* mul] [+ res].  gamma/beta None -> plain activation (no normalisation)."""
 
@@ -554,28 +559,38 @@ class _BNAct(torch.autograd.Function):
         B, H, W, Cs = x.shape
         M = B * H * W
         mean = invstd = None
+        if mul is not None:
+            mul = _req(mul, "mul")
+        if res is not None:
+            res = _req(res, "res")
+        y = _empty(x.shape, x)
+        fused = False
         if gamma is not None:
             mean, invstd = _empty((Cs,), x), _empty((Cs,), x)
             if training:
                 if stats is not None:
                     partial, nblk = stats, stats.shape[0]
                     rpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, Cs)
+                    if nblk <= _BN_FUSE_ROWS:
+                        # few statistics rows: every thread merges them itself, no separate finalize launch
+                        _k("vmtl_bn_apply_fused", x=x, partial=partial, nblk=nblk, rows_per_blk=rpb, eps=eps,
+                           momentum=momentum, running_mean=running_mean, running_var=running_var,
+                           num_batches_tracked=nbt, save_mean=mean, save_invstd=invstd, gamma=gamma, beta=beta, mul=mul,
+                           res=res, y=y, M=M, C=C, Cs=Cs, act=act)
+                        fused = True
                 else:
                     partial, nblk, rpb = _empty((_reduce_rows(M), 2, Cs), x), 0, 0
-                _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk,
-                   rows_per_blk_from_conv=rpb, eps=eps,
-                   momentum=momentum, running_mean=running_mean, running_var=running_var, num_batches_tracked=nbt,
-                   save_mean=mean, save_invstd=invstd)
+                if not fused:
+                    _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk,
+                       rows_per_blk_from_conv=rpb, eps=eps,
+                       momentum=momentum, running_mean=running_mean, running_var=running_var, num_batches_tracked=nbt,
+                       save_mean=mean, save_invstd=invstd)
             else:
                 _k("vmtl_bn_eval_stats", running_mean=running_mean, running_var=running_var, C=C, Cs=Cs, eps=eps,
                    save_mean=mean, save_invstd=invstd)
-        if mul is not None:
-            mul = _req(mul, "mul")
-        if res is not None:
-            res = _req(res, "res")
-        y = _empty(x.shape, x)
-        _k("vmtl_bn_apply", x=x, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=mul, res=res, y=y, M=M, C=C,
-           Cs=Cs, act=act)
+        if not fused:
+            _k("vmtl_bn_apply", x=x, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=mul, res=res, y=y, M=M, C=C,
+               Cs=Cs, act=act)
         ctx.save_for_backward(x, gamma, beta, mean, invstd, mul)
         ctx.cfg = (C, training, act, res is not None)
         ctx.slots = (_slot(gamma), _slot(beta))
