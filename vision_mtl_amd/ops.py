@@ -117,6 +117,7 @@ class _SideBranch:
         if pend:
             for s in pend:
                 torch.cuda.current_stream(s.device).wait_stream(s)
+        packs.join()
 
     def mark(self):
         """Record the fork point on the current (main) stream.  Taken on entry of a backward function so the
@@ -166,26 +167,52 @@ class _PackCache:
 
     def __init__(self):
         self.entries = {}  # key -> dict(dst, params, weight_ref, ptr, version, epoch)
+        self.custom = {}   # key -> dict(dst, fn, weight, ptr, version, epoch): operands with their own pack kernel
         self.epoch = 0
         self.table = None  # (device uint8 tensor, n, total)
         self.dirty = True
+        self.custom_ready = None  # event: this step's custom operands are packed (side stream)
 
     def invalidate(self):
         self.epoch += 1
 
-    def get(self, weight, kind, params):
-        key = (id(weight), kind, params)
+    def get(self, weight, kind, params, offset=0):
+        """params = (R1, R0, T, C, Cs, sr1, sr0, st, sc, flip); offset = first element of the weight to read."""
+        key = (id(weight), kind, params, offset)
         e = self.entries.get(key)
         if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
             return e["dst"]
         R1, R0, T, C, Cs = params[:5]
         if e is None or e["ptr"] != weight.data_ptr():
-            e = {"dst": _empty((R1 * R0, T * Cs), weight), "params": params, "weight": weight, "ptr": weight.data_ptr()}
+            e = {"dst": _empty((R1 * R0, T * Cs), weight), "params": params, "weight": weight, "ptr": weight.data_ptr(),
+                 "offset": offset}
             self.entries[key] = e
             self.dirty = True
-        pack(weight, *params, out=e["dst"])
+        pack(weight.view(-1)[offset:] if offset else weight, *params, out=e["dst"])
         e["version"], e["epoch"] = weight._version, self.epoch
         return e["dst"]
+
+    def get_custom(self, weight, kind, shape, fn):
+        """Operand built by its own kernel (fn(weight, dst) launches it): cached like get(); refresh() rebuilds
+        all of them on the side stream at the start of a step, so inside the step this is a lookup (+ one
+        event wait on first use)."""
+        key = (id(weight), kind)
+        e = self.custom.get(key)
+        if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
+            self.join()
+            return e["dst"]
+        if e is None or e["ptr"] != weight.data_ptr():
+            e = {"dst": _empty(shape, weight), "fn": fn, "weight": weight, "ptr": weight.data_ptr()}
+            self.custom[key] = e
+        fn(weight, e["dst"])
+        e["version"], e["epoch"] = weight._version, self.epoch
+        return e["dst"]
+
+    def join(self):
+        """Make the current stream wait for the side-stream packing of this step (no-op when already waited)."""
+        ev, self.custom_ready = self.custom_ready, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def _build_table(self):
         import struct
@@ -199,8 +226,8 @@ class _PackCache:
         recs, start = [], 0
         for e in live:
             R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
-            recs.append(struct.pack("<QQqqqqqiiiiii", e["ptr"], e["dst"].data_ptr(), sr1, sr0, st, sc, start, R1, R0, T,
-                                    C, Cs, flip))
+            recs.append(struct.pack("<QQqqqqqiiiiii", e["ptr"] + 4 * e.get("offset", 0), e["dst"].data_ptr(), sr1, sr0,
+                                    st, sc, start, R1, R0, T, C, Cs, flip))
             start += R1 * R0 * T * Cs
         size = lib().raw("vmtl_pack_desc_bytes")()
         blob = b"".join(r.ljust(size, b"\0") for r in recs)
@@ -210,19 +237,39 @@ class _PackCache:
 
     def refresh(self):
         """Re-pack every known weight (call once at the start of a step, before the forward)."""
-        if not self.entries:
+        self.join()
+        if not self.entries and not self.custom:
             return
         self.epoch += 1
         if self.dirty:
             if torch.cuda.is_current_stream_capturing():
                 return  # keep per-call packing inside this capture; the table is rebuilt on the next eager step
             self._build_table()
-        if self.table is None:
-            return
-        table, n, total = self.table
-        _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
-        for e in self.live:
-            e["version"], e["epoch"] = e["weight"]._version, self.epoch
+        if self.table is not None:
+            table, n, total = self.table
+            _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
+            for e in self.live:
+                e["version"], e["epoch"] = e["weight"]._version, self.epoch
+        # operands with their own pack kernels (up2 phase / gradient matrices): none is needed before the
+        # decoder, so they are built on the side stream while the encoder runs
+        self.custom = {k: e for k, e in self.custom.items() if e["weight"].data_ptr() == e["ptr"]}
+        if self.custom:
+            use_side = side.enabled
+            if use_side:
+                main = torch.cuda.current_stream()
+                s = side.stream(main.device)
+                s.wait_stream(main)
+                ctx = torch.cuda.stream(s)
+            else:
+                ctx = contextlib.nullcontext()
+            with ctx:
+                for e in self.custom.values():
+                    e["fn"](e["weight"], e["dst"])
+                    e["version"], e["epoch"] = e["weight"]._version, self.epoch
+                if use_side:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self.custom_ready = ev
 
 
 packs = _PackCache()
@@ -366,8 +413,8 @@ class _Up2Conv(torch.autograd.Function):
             raise ValueError(f"up2_conv: weight has {Cin} input channels, sources hold {C0s}+{C1s} storage channels")
         ldy = ceil4(Cout)
         Ktot = 4 * C0s + 9 * C1s
-        wp = _empty((4, Cout, Ktot), xl)
-        _k("vmtl_pack_up2_fwd", w=weight, dst=wp, Cout=Cout, C0=C0, C0s=C0s, C1=C1, C1s=C1s)
+        wp = packs.get_custom(weight, "up2_fwd", (4, Cout, Ktot), lambda w, dst: _k(
+            "vmtl_pack_up2_fwd", w=w, dst=dst, Cout=Cout, C0=C0, C0s=C0s, C1=C1, C1s=C1s))
         y = _empty((B, 2 * H2, 2 * W2, ldy), xl)
         stats = None
         if want_stats:
@@ -401,14 +448,14 @@ class _Up2Conv(torch.autograd.Function):
         stamp(f"main up2 M={B * H * W} N={Cout} Cin={Cin}")
         fork = side.mark()
         if ctx.needs_input_grad[0]:  # 4x4 / stride 2 / pad 1 convolution over dY with pre-summed taps
-            wd = _empty((C0, 16 * ldy), xl)
-            _k("vmtl_pack_up2_dgrad", w=weight, dst=wd, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin)
+            wd = packs.get_custom(weight, "up2_dgrad", (C0, 16 * ldy), lambda w, dst: _k(
+                "vmtl_pack_up2_dgrad", w=w, dst=dst, Cout=Cout, Cos=ldy, C0=C0, Cin=Cin))
             dxl = _empty((B, H2, W2, C0s), xl)
             _conv_launch(dy, wd, None, dxl, None, B, H, W, ldy, H2, W2, C0s, C0, C0, 4, 4, 2, 1, cin=Cout,
                          algo_flop=2.0 * B * H * W * C0 * 9 * Cout)
         if skip is not None and ctx.needs_input_grad[1]:  # plain 3x3 data gradient restricted to the skip channels
             C1s = skip.shape[3]
-            wds = pack(weight.view(-1)[C0 * 9:], 1, C1, 9, Cout, ldy, 0, 9, 1, Cin * 9, flip=1)
+            wds = packs.get(weight, "up2_dskip", (1, C1, 9, Cout, ldy, 0, 9, 1, Cin * 9, 1), offset=C0 * 9)
             dskip = _empty((B, H, W, C1s), xl)
             _conv_launch(dy, wds, None, dskip, None, B, H, W, ldy, H, W, C1s, C1, C1, 3, 3, 1, 1, cin=Cout)
         if ctx.needs_input_grad[2]:
