@@ -29,6 +29,8 @@ extern "C" {
 #define VMTL_ACT_SIGMOID 4
 
 const char* vmtl_version(void);
+/* HIP's text for the last launch failure (status -2) seen on the calling thread */
+const char* vmtl_last_error_string(void);
 /* tuning aid: *out = 100 MHz device wall clock at the moment `stream` gets there */
 int vmtl_timestamp(long long* out, void* stream);
 

@@ -45,3 +45,25 @@ def test_callk_rejects_wrong_names():
 
     with pytest.raises(TypeError):
         lib().callk("vmtl_maxpool2_fwd", x=None, y=None, B=1, H=2, W=2, Cs=4)  # stream missing
+
+
+def test_torch_hip_runtime_is_loaded_before_the_extension():
+    """libvmtl.so must resolve against the libamdhip64.so PyTorch-ROCm ships (streams / pointers come from
+    torch): _lib imports torch before dlopen-ing it.  Loaded first, the extension binds to /opt/rocm's
+    runtime and every launch fails with "no ROCm-capable device" (seen with build() followed by smoke()
+    in one process).  Checked in a fresh interpreter via the order of the mappings in /proc/self/maps."""
+    import subprocess
+    import sys
+
+    code = (
+        "import re\n"
+        "from vision_mtl_amd import _lib\n"
+        "_lib.lib()\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "hip = sorted(set(re.findall(r'(/\\S*libamdhip64[^\\s]*)', maps)))\n"
+        "assert any('/torch/' in p for p in hip), hip\n"
+        "assert not any(p.startswith('/opt/rocm') for p in hip), hip\n"
+        "print('ok', hip)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    assert r.returncode == 0, r.stdout + r.stderr

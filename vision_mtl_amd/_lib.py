@@ -13,6 +13,11 @@ import re
 import subprocess
 from pathlib import Path
 
+# torch first: PyTorch-ROCm ships its own libamdhip64.so, and libvmtl.so must bind to THAT copy of the HIP
+# runtime (streams and device pointers come from torch).  Loaded the other way round, the dynamic loader
+# resolves libvmtl.so against /opt/rocm's runtime and its launches fail with "no ROCm-capable device".
+import torch  # noqa: F401
+
 _PKG = Path(__file__).resolve().parent
 CSRC = _PKG / "csrc"
 LIB_PATH = CSRC / "libvmtl.so"
@@ -88,6 +93,8 @@ class _Lib:
         rc = self._fn[name](*args)
         if rc != 0:
             what = {-1: "bad argument", -2: "kernel launch failure", -3: "unsupported configuration"}.get(rc, "error")
+            if rc == -2:
+                what += ": " + self._fn["vmtl_last_error_string"]().decode()
             raise RuntimeError(f"{name} failed: {what} (status {rc})")
 
 

@@ -132,6 +132,7 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
                              int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var,
                              long long* num_batches_tracked, float* save_mean, float* save_invstd, void* stream) {
+  VMTL_ENTER();
   if (!partial || !save_mean || !save_invstd || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = nblk_from_conv, rows_per_blk = rows_per_blk_from_conv;
@@ -150,6 +151,7 @@ extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partia
 
 extern "C" int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int C, int Cs, float eps,
                                   float* save_mean, float* save_invstd, void* stream) {
+  VMTL_ENTER();
   if (!running_mean || !running_var || !save_mean || !save_invstd || C <= 0 || C > Cs) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
                      running_var, C, Cs, eps, save_mean, save_invstd);
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(RED_THREADS) void bn_apply_fused_kernel(
 extern "C" int vmtl_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, const float* mul, const float* res, float* y, long long M, int C,
                              int Cs, int act, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || M <= 0 || M > 0x7fffffffLL || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
   if ((mean == nullptr) != (invstd == nullptr)) return VMTL_ERR_ARG;
   const int nb = sweep_blocks(M, Cs);
@@ -323,6 +326,7 @@ extern "C" int vmtl_bn_apply_fused(const float* x, const float* partial, int nbl
                                    long long* num_batches_tracked, float* save_mean, float* save_invstd,
                                    const float* gamma, const float* beta, const float* mul, const float* res, float* y,
                                    long long M, int C, int Cs, int act, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || !partial || !save_mean || !save_invstd || M <= 0 || M > 0x7fffffffLL || C <= 0 || C > Cs || (Cs & 3))
     return VMTL_ERR_ARG;
   if (nblk <= 0 || nblk > VMTL_BN_FUSE_MAX_ROWS || rows_per_blk <= 0 || (long long)nblk * rows_per_blk < M)
@@ -442,6 +446,7 @@ extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, c
                            const float* gamma, const float* beta, const float* mul, float* dmul, float* partial,
                            float* sum_dz, float* sum_dzx, float* dx, int M, int C, int Cs, int act, int training,
                            void* stream) {
+  VMTL_ENTER();
   if (!x || !dy || !dx || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
   if ((mean == nullptr) != (invstd == nullptr)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -496,6 +501,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 
 extern "C" int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
                            float* partial, float* out, void* stream) {
+  VMTL_ENTER();
   if (!a || !partial || !out || M <= 0 || C <= 0 || C > Cs || (Cs & 3) || (mode == 1 && !b)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = red_blocks(M);

@@ -25,8 +25,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Every launching entry point starts with VMTL_ENTER(): hipGetLastError() is per-thread state shared with
+// every other HIP user in the process (e.g. an ignored status inside the framework that hosts us), and
+// the status returned by vmtl_check_launch() must describe OUR launch only.
+#define VMTL_ENTER() ((void)hipGetLastError())
+
+extern thread_local int vmtl_last_hip_error;  // version.hip; read back with vmtl_last_error_string()
+
 static inline int vmtl_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) vmtl_last_hip_error = (int)e;
   return e == hipSuccess ? VMTL_OK : VMTL_ERR_LAUNCH;
 }
 

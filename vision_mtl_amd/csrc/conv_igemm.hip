@@ -837,6 +837,7 @@ extern "C" int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot) {
 extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
                                int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
                                int KH, int KW, int stride, int pad, int act, int shuffle, void* stream) {
+  VMTL_ENTER();
   if (!x || !wp || !y) return VMTL_ERR_ARG;
   if (Cs <= 0 || (Cs & 3) || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return VMTL_ERR_ARG;
   if (KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || Nw <= 0 || Cout <= 0 || ldy <= 0) return VMTL_ERR_ARG;
@@ -878,6 +879,7 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
 extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int B, int H, int W, int Cs,
                                   int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride, int pad,
                                   void* stream) {
+  VMTL_ENTER();
   const int splits = vmtl_conv2d_ksplit(B, Ho, Wo, ldy, KH * KW * Cs);
   if (splits <= 1 || ws == nullptr)
     return vmtl_conv2d_fwd(x, wp, nullptr, y, nullptr, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, 0, 0, stream);
@@ -940,6 +942,7 @@ extern "C" int vmtl_conv2d_up2_stats_block(int B, int H2, int W2, int ldy) {
 // stats (optional): [4 * ceil(B*H2*W2 / block)][2][ldy]; only valid when block divides B*H2*W2
 extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const float* wp_eff, float* y, float* stats,
                                    int B, int H2, int W2, int C0s, int C1s, int ldy, int Cout, void* stream) {
+  VMTL_ENTER();
   if (!xl || !wp_eff || !y || B <= 0 || H2 <= 0 || W2 <= 0 || C0s <= 0 || (C0s & 3) || (C1s & 3) || C1s < 0)
     return VMTL_ERR_ARG;
   if ((skip == nullptr) != (C1s == 0) || Cout <= 0 || Cout > ldy) return VMTL_ERR_ARG;
@@ -1036,6 +1039,7 @@ static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
 extern "C" int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits, int B, int H, int W,
                                  int Cs, int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad,
                                  void* stream) {
+  VMTL_ENTER();
   if (!x || !dy || !slabs) return VMTL_ERR_ARG;
   if (Cs <= 0 || (Cs & 3) || (ldy & 3) || Nw <= 0 || Nw > ldy) return VMTL_ERR_ARG;
   if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return VMTL_ERR_ARG;

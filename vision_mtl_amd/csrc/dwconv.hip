@@ -148,6 +148,7 @@ static int dw_check(int B, int H, int W, int Cs, int Ho, int Wo, int K, int stri
 
 extern "C" int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B, int H, int W, int Cs, int Ho, int Wo,
                                int K, int stride, int pad, void* stream) {
+  VMTL_ENTER();
   if (!x || !wp || !y) return VMTL_ERR_ARG;
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   const long long total4 = (long long)B * Ho * Wo * (Cs >> 2);
@@ -158,6 +159,7 @@ extern "C" int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B,
 
 extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
                                     int Wo, int K, int stride, int pad, void* stream) {
+  VMTL_ENTER();
   if (!dy || !wp || !dx) return VMTL_ERR_ARG;
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   const long long total4 = (long long)B * H * W * (Cs >> 2);
@@ -169,6 +171,7 @@ extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx,
 // partial: at least 256 * K*K * Cs floats (vmtl_reduce_rows(M) * K*K * Cs always suffices).  dw: torch (C,1,K,K) layout.
 extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,
                                       int C, int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream) {
+  VMTL_ENTER();
   if (!x || !dy || !partial || !dw || C <= 0 || C > Cs) return VMTL_ERR_ARG;
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   hipStream_t st = (hipStream_t)stream;

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void concat2_bwd_kernel(const float* __restric
 extern "C" int vmtl_concat2(const float* a, int Ha, int Wa, int Ca, int Csa, int upa, int oha, int owa,
                             const float* b, int Hb, int Wb, int Cb, int Csb, int upb, int ohb, int owb, float* y,
                             int B, int H, int W, int Cd, void* stream) {
+  VMTL_ENTER();
   if (!a || !y || B <= 0 || Ca + Cb > Cd || (Cd & 3) || (Csa & 3) || (Cb && (Csb & 3)) || (upa != 1 && upa != 2))
     return VMTL_ERR_ARG;
   if ((long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
@@ -128,6 +129,7 @@ extern "C" int vmtl_concat2(const float* a, int Ha, int Wa, int Ca, int Csa, int
 
 extern "C" int vmtl_concat2_bwd(const float* dy, float* dx, int B, int H, int W, int Cd, int c_off, int Hs, int Ws,
                                 int C, int Cs, int up, int oh, int ow, void* stream) {
+  VMTL_ENTER();
   if (!dy || !dx || c_off < 0 || c_off + C > Cd || (Cs & 3) || (Cd & 3) || (up != 1 && up != 2)) return VMTL_ERR_ARG;
   if ((long long)B * Hs * Ws > 0x7fffffffLL) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * Hs * Ws * (Cs >> 2);
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 }
 
 extern "C" int vmtl_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || (Cs & 3) || (H & 1) || (W & 1) || H < 2 || W < 2) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * (H / 2) * (W / 2) * (Cs >> 2);
   hipLaunchKernelGGL(maxpool2_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, Cs,
@@ -206,6 +209,7 @@ extern "C" int vmtl_maxpool2_fwd(const float* x, float* y, int B, int H, int W, 
 
 extern "C" int vmtl_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int Cs,
                                  void* stream) {
+  VMTL_ENTER();
   if (!x || !dy || !dx || (Cs & 3) || (H & 1) || (W & 1) || H < 2 || W < 2) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * (H / 2) * (W / 2) * (Cs >> 2);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, B, H,
@@ -292,6 +296,7 @@ static inline float bil_scale(int in_size) {
 }
 
 extern "C" int vmtl_bilinear_up2_fwd(const float* x, float* y, int B, int H, int W, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || (Cs & 3) || B <= 0 || H <= 0 || W <= 0) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * 4 * H * W * (Cs >> 2);
   hipLaunchKernelGGL(bilinear_up2_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, Cs,
@@ -300,6 +305,7 @@ extern "C" int vmtl_bilinear_up2_fwd(const float* x, float* y, int B, int H, int
 }
 
 extern "C" int vmtl_bilinear_up2_bwd(const float* dy, float* dx, int B, int H, int W, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!dy || !dx || (Cs & 3) || B <= 0 || H <= 0 || W <= 0) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * H * W * (Cs >> 2);
   hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, dx, B, H,
@@ -365,6 +371,7 @@ __global__ __launch_bounds__(256) void channel_scale_bwd_s_kernel(const float* _
 }
 
 extern "C" int vmtl_spatial_mean(const float* x, float* y, int B, int HW, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || (Cs & 3) || B <= 0 || HW <= 0) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(spatial_mean_kernel, dim3(cdiv(Cs >> 2, 64), B), dim3(256), 0, (hipStream_t)stream, x, y, HW, Cs);
   return vmtl_check_launch();
@@ -372,6 +379,7 @@ extern "C" int vmtl_spatial_mean(const float* x, float* y, int B, int HW, int Cs
 
 extern "C" int vmtl_channel_bcast(const float* x, const float* s, float* y, int B, int HW, int Cs, int mode,
                                   void* stream) {
+  VMTL_ENTER();
   if (!s || !y || (mode == 0 && !x) || (Cs & 3) || B <= 0 || HW <= 0) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * HW * (Cs >> 2);
   hipLaunchKernelGGL(channel_bcast_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, s, y, HW, Cs,
@@ -381,6 +389,7 @@ extern "C" int vmtl_channel_bcast(const float* x, const float* s, float* y, int 
 
 extern "C" int vmtl_channel_scale_bwd_s(const float* x, const float* dy, float* ds, int B, int HW, int Cs,
                                         void* stream) {
+  VMTL_ENTER();
   if (!x || !dy || !ds || (Cs & 3) || B <= 0 || HW <= 0) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(channel_scale_bwd_s_kernel, dim3(cdiv(Cs >> 2, 64), B), dim3(256), 0, (hipStream_t)stream, x, dy,
                      ds, HW, Cs);
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(256) void stitch_kernel(const float* __restrict__ x
 
 extern "C" int vmtl_stitch(const float* x, const float* w, float* y, long long M, int C, int Cs, int wstride,
                            void* stream) {
+  VMTL_ENTER();
   if (!x || !w || !y || (Cs & 3) || M <= 0 || C > Cs) return VMTL_ERR_ARG;
   const long long total4 = M * (Cs >> 2);
   hipLaunchKernelGGL(stitch_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, w, y, C, Cs, wstride,
@@ -431,6 +441,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
 }
 
 extern "C" int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream) {
+  VMTL_ENTER();
   if (!a || !y || total <= 0 || mode < 0 || mode > 3 || (mode != 1 && !b)) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(ew_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, b, y, mode, total);
   return vmtl_check_launch();
@@ -455,6 +466,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ z
 
 extern "C" int vmtl_argmax_channels(const float* z, long long* out, int B, int HW, int C, long long sb, long long sc,
                                     long long sp, void* stream) {
+  VMTL_ENTER();
   if (!z || !out || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   const long long P = (long long)B * HW;
   hipLaunchKernelGGL(argmax_kernel, dim3(ew_grid(P)), dim3(256), 0, (hipStream_t)stream, z, out, HW, C, sb, sc, sp, P);
@@ -488,6 +500,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 
 extern "C" int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, int Cw, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || C > Cw || Cw > Cs || B <= 0) return VMTL_ERR_ARG;
   const long long total = (long long)B * HW * Cw;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cs,
@@ -496,6 +509,7 @@ extern "C" int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW,
 }
 
 extern "C" int vmtl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!x || !y || C > Cs || B <= 0) return VMTL_ERR_ARG;
   const long long total = (long long)B * C * HW;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cs,

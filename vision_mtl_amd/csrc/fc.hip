@@ -117,6 +117,7 @@ extern "C" int vmtl_fc_max_rows() { return 64; }
 extern "C" int vmtl_fc_fwd(const float* a, int a_parts, long long a_part_stride, float a_scale, const float* a_z,
                            int a_act, float* a_out, const float* w, const float* bias, float* z, float* y, int M,
                            int K, int N, int lda, int ldw, int ldy, int act, void* stream) {
+  VMTL_ENTER();
   if (!a || !w || !y || M <= 0 || M > 64 || K <= 0 || N <= 0 || (lda & 3) || lda < K || ldw < K || ldy < N ||
       a_parts < 1 || (a_parts > 1 && (a_part_stride & 3)))
     return VMTL_ERR_ARG;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256) void fc_wgrad_kernel(FcWgP p) {
 extern "C" int vmtl_fc_wgrad(const float* x, int x_parts, long long x_part_stride, float x_scale, const float* dyo,
                              int dy_parts, long long dy_part_stride, const float* zo, float* dw, float* db, int M,
                              int K, int N, int lda, int ldn, int act, void* stream) {
+  VMTL_ENTER();
   if (!x || !dyo || !dw || M <= 0 || M > 64 || K <= 0 || N <= 0 || lda < K || ldn < N || x_parts < 1 || dy_parts < 1)
     return VMTL_ERR_ARG;
   FcWgP p{x, dyo, zo, dw, db, x_part_stride, dy_part_stride, x_scale, x_parts, dy_parts, M, K, N, lda, ldn, act};
@@ -273,6 +275,7 @@ extern "C" int vmtl_hw_reduce_parts(int B, int HW, int Cs) {
 }
 
 extern "C" int vmtl_hw_reduce(const float* x, const float* y, float* part, int B, int HW, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!x || !part || (Cs & 3) || B <= 0 || HW <= 0) return VMTL_ERR_ARG;
   const int S = vmtl_hw_reduce_parts(B, HW, Cs);
   const int rows_per = cdiv(HW, S);
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(256) void channel_scale_add_kernel(const float* __r
 
 extern "C" int vmtl_channel_scale_add(const float* x, const float* s, const float* t, float t_scale, float* y, int B,
                                       int HW, int Cs, void* stream) {
+  VMTL_ENTER();
   if (!x || !s || !y || (Cs & 3) || B <= 0 || HW <= 0) return VMTL_ERR_ARG;
   const long long total4 = (long long)B * HW * (Cs >> 2);
   long long blocks = (total4 + 255) / 256;

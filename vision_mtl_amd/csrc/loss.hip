@@ -95,6 +95,7 @@ extern "C" long long vmtl_ce_workspace_bytes(long long P) { return ((long long)c
 // (non-zero after the call = some target outside [0, C)).
 extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void* workspace, int B, int HW,
                            int C, long long sb, long long sc, long long sp, void* stream) {
+  VMTL_ENTER();
   if (!logits || !target || !loss || !workspace || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)B * HW;
@@ -110,6 +111,7 @@ extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* 
 
 extern "C" int vmtl_ce_bwd(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
                            int HW, int C, long long sb, long long sc, long long sp, void* stream) {
+  VMTL_ENTER();
   if (!logits || !target || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   const long long P = (long long)B * HW;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target,
@@ -198,6 +200,7 @@ extern "C" long long vmtl_silog_workspace_bytes(long long P) { return (long long
 
 extern "C" int vmtl_silog_fwd(const float* pred, const float* target, float min_depth, float* loss, float* stats,
                               void* workspace, long long P, void* stream) {
+  VMTL_ENTER();
   if (!pred || !target || !loss || !stats || !workspace || P <= 0) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = sl_blocks(P);
@@ -208,6 +211,7 @@ extern "C" int vmtl_silog_fwd(const float* pred, const float* target, float min_
 
 extern "C" int vmtl_silog_bwd(const float* pred, const float* target, const float* stats, const float* grad_out,
                               float min_depth, float* dpred, long long P, void* stream) {
+  VMTL_ENTER();
   if (!pred || !target || !stats || !grad_out || !dpred || P <= 0) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(silog_bwd_kernel, dim3(sl_blocks(P)), dim3(256), 0, (hipStream_t)stream, pred, target, stats,
                      grad_out, min_depth, P, dpred);
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ p
 
 extern "C" int vmtl_l1_fwd(const float* pred, const float* target, float* loss, void* workspace, long long P,
                            void* stream) {
+  VMTL_ENTER();
   if (!pred || !target || !loss || !workspace || P <= 0) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = sl_blocks(P);
@@ -248,6 +253,7 @@ extern "C" int vmtl_l1_fwd(const float* pred, const float* target, float* loss, 
 
 extern "C" int vmtl_l1_bwd(const float* pred, const float* target, const float* grad_out, float* dpred, long long P,
                            void* stream) {
+  VMTL_ENTER();
   if (!pred || !target || !grad_out || !dpred || P <= 0) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(l1_bwd_kernel, dim3(sl_blocks(P)), dim3(256), 0, (hipStream_t)stream, pred, target, grad_out, P,
                      dpred);

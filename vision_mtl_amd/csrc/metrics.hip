@@ -51,6 +51,7 @@ __global__ void segm_metrics_kernel(const int* __restrict__ cm, int C, float bet
 
 extern "C" int vmtl_confusion_matrix(const long long* pred, const long long* target, int* cm, long long P, int C,
                                      void* stream) {
+  VMTL_ENTER();
   if (!pred || !target || !cm || P <= 0 || C <= 0 || C > CM_MAX_C) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(cm, 0, (size_t)C * C * sizeof(int), st) != hipSuccess) return VMTL_ERR_LAUNCH;
@@ -63,6 +64,7 @@ extern "C" int vmtl_confusion_matrix(const long long* pred, const long long* tar
 }
 
 extern "C" int vmtl_segm_metrics(const int* cm, int C, float beta, float* out, void* stream) {
+  VMTL_ENTER();
   if (!cm || !out || C <= 0 || C > CM_MAX_C) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(segm_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cm, C, beta, out);
   return vmtl_check_launch();

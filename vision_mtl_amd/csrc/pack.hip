@@ -69,6 +69,7 @@ extern "C" int vmtl_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
 // descs: device array of n descriptors laid out as struct PackDesc (see vmtl_pack_desc_bytes);
 // total = sum of R1*R0*T*Cs over the table.
 extern "C" int vmtl_pack_weights_batch(const void* descs, int n, long long total, void* stream) {
+  VMTL_ENTER();
   if (!descs || n <= 0 || total <= 0) return VMTL_ERR_ARG;
   long long nb = cdivll(total, 256);
   if (nb > 8192) nb = 8192;
@@ -145,6 +146,7 @@ static inline int pk_grid(long long total) {
 
 extern "C" int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
                                  long long sr0, long long st, long long sc, int flip, void* stream) {
+  VMTL_ENTER();
   if (!src || !dst || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs) return VMTL_ERR_ARG;
   const long long total = (long long)R1 * R0 * T * Cs;
   hipLaunchKernelGGL(pack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, R1, R0, T, C, Cs,
@@ -154,6 +156,7 @@ extern "C" int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, i
 
 extern "C" int vmtl_pack_weights_slice(const float* src, float* dst, int R0, int T, int C, int group, long long sr0,
                                        long long st, long long sc, int flip, void* stream) {
+  VMTL_ENTER();
   if (!src || !dst || R0 <= 0 || T <= 0 || C <= 0 || C > group) return VMTL_ERR_ARG;
   const long long total = (long long)R0 * T * C;
   hipLaunchKernelGGL(pack_slice_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, R0, T, C,
@@ -164,6 +167,7 @@ extern "C" int vmtl_pack_weights_slice(const float* src, float* dst, int R0, int
 extern "C" int vmtl_unpack_weights(const float* packed, float* grad, int R1, int R0, int T, int C, int Cs,
                                    long long sr1, long long sr0, long long st, long long sc, int flip, int nslabs,
                                    long long slab_stride, void* stream) {
+  VMTL_ENTER();
   if (!packed || !grad || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs || nslabs <= 0) return VMTL_ERR_ARG;
   if (slab_stride <= 0) slab_stride = (long long)R1 * R0 * T * Cs;  // slabs hold exactly these rows
   const long long total = (long long)R1 * R0 * T * C;
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256) void unpack_up2_kernel(const float* __restrict
 }
 
 extern "C" int vmtl_pack_up2_fwd(const float* w, float* dst, int Cout, int C0, int C0s, int C1, int C1s, void* stream) {
+  VMTL_ENTER();
   if (!w || !dst || Cout <= 0 || C0 <= 0 || C0 > C0s || C1 < 0 || C1 > C1s) return VMTL_ERR_ARG;
   const long long total = 4ll * Cout * (4 * C0s + 9 * C1s);
   hipLaunchKernelGGL(pack_up2_fwd_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, C0,
@@ -262,6 +267,7 @@ extern "C" int vmtl_pack_up2_fwd(const float* w, float* dst, int Cout, int C0, i
 }
 
 extern "C" int vmtl_pack_up2_dgrad(const float* w, float* dst, int Cout, int Cos, int C0, int Cin, void* stream) {
+  VMTL_ENTER();
   if (!w || !dst || Cout <= 0 || Cout > Cos || C0 <= 0 || C0 > Cin) return VMTL_ERR_ARG;
   const long long total = (long long)C0 * 16 * Cos;
   hipLaunchKernelGGL(pack_up2_dgrad_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, w, dst, Cout, Cos,
@@ -271,6 +277,7 @@ extern "C" int vmtl_pack_up2_dgrad(const float* w, float* dst, int Cout, int Cos
 
 extern "C" int vmtl_unpack_up2(const float* slabs, float* grad, int Cout, int Cos, int C0, int Cin, int nslabs,
                                void* stream) {
+  VMTL_ENTER();
   if (!slabs || !grad || Cout <= 0 || Cout > Cos || C0 <= 0 || C0 > Cin || nslabs <= 0) return VMTL_ERR_ARG;
   const long long total = (long long)C0 * 9 * Cout;
   hipLaunchKernelGGL(unpack_up2_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, slabs, grad, Cout,
@@ -304,6 +311,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int vmtl_adam_step(float* p, const float* g, float* m, float* v, const float* step_ptr, float lr, float b1,
                               float b2, float eps, float weight_decay, float grad_scale, long long n, void* stream) {
+  VMTL_ENTER();
   if (!p || !g || !m || !v || !step_ptr || n <= 0) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(pk_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, step_ptr, lr, b1,
                      b2, eps, weight_decay, grad_scale, n);
