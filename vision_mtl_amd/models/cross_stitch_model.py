@@ -11,6 +11,7 @@ corresponding HIP kernel; the walk is compiled once into a flat program.
 """
 from __future__ import annotations
 
+import contextlib
 import re
 import typing as t
 
@@ -48,7 +49,10 @@ class CrossStitchLayer(nn.Module):
         nn.init.uniform_(self.weights)
 
     def run(self, acts: t.List[L.Act]) -> t.List[L.Act]:
-        return [L.Act(ops.stitch(a.t, self.weights, i, a.C), a.C) for i, a in enumerate(acts)]
+        return [self.run_task(i, a) for i, a in enumerate(acts)]
+
+    def run_task(self, i: int, a: L.Act) -> L.Act:
+        return L.Act(ops.stitch(a.t, self.weights, i, a.C), a.C)
 
     def forward(self, mt_activations: torch.Tensor) -> torch.Tensor:
         """(T, B, C, H, W) -> (T, B, C, H, W), as the reference's einsum."""
@@ -162,24 +166,33 @@ class CSNet(nn.Module):
         x0 = L.from_nchw(x)
         feats = {task: x0 for task in self.model_names}
         skips = {task: [] for task in self.model_names}
+        # Two task networks that never exchange data (the stitch only scales a task's own features): the
+        # second one runs on its own stream - a parallel branch of the captured graph - and is joined at the end.
+        main = torch.cuda.current_stream() if x.is_cuda else None
+        streams = {task: None for task in self.model_names}
+        if (main is not None and ops.side.enabled and ops.side.task_parallel and self.num_tasks == 2
+                and self.debug_acts is None):
+            s1 = ops.side.task_stream(x.device)
+            s1.wait_stream(main)
+            x0.t.record_stream(s1)
+            streams[self.model_names[1]] = s1
         for op, arg in self._program:
-            if op == "stitch":
-                outs = self.cross_stitch_layers[arg].run([feats[task] for task in self.model_names])
-                feats = dict(zip(self.model_names, outs))
-                continue
-            for task in self.model_names:
-                net, f = self.models[task], feats[task]
-                if op == "save":
-                    skips[task].append(f)
-                elif op == "merge":
-                    feats[task] = L.pad_cat(f, skips[task][-arg - 1])
-                elif op == "up":
-                    feats[task] = L.up2_cat(f, None)
-                elif op == "leaf":
-                    feats[task] = self._apply_leaf(get_module_by_name(net, arg), f)
-                else:  # conv_bn_relu
-                    feats[task] = L.conv_bn_act(f, get_module_by_name(net, arg[0]), get_module_by_name(net, arg[1]),
-                                                ops.ACT_RELU)
+            for ti, task in enumerate(self.model_names):
+                with (torch.cuda.stream(streams[task]) if streams[task] is not None else contextlib.nullcontext()):
+                    net, f = self.models[task], feats[task]
+                    if op == "stitch":
+                        feats[task] = self.cross_stitch_layers[arg].run_task(ti, f)
+                    elif op == "save":
+                        skips[task].append(f)
+                    elif op == "merge":
+                        feats[task] = L.pad_cat(f, skips[task][-arg - 1])
+                    elif op == "up":
+                        feats[task] = L.up2_cat(f, None)
+                    elif op == "leaf":
+                        feats[task] = self._apply_leaf(get_module_by_name(net, arg), f)
+                    else:  # conv_bn_relu
+                        feats[task] = L.conv_bn_act(f, get_module_by_name(net, arg[0]), get_module_by_name(net, arg[1]),
+                                                    ops.ACT_RELU)
                 if self.debug_acts is not None and op in ("merge", "up", "conv_bn_relu"):
                     rec = [op, arg, task, L.to_nchw(feats[task]).detach().cpu(), None]
                     if feats[task].t.requires_grad:
@@ -187,4 +200,13 @@ class CSNet(nn.Module):
                         feats[task].t.register_hook(
                             lambda g, rec=rec, C=C: rec.__setitem__(4, g[..., :C].permute(0, 3, 1, 2).detach().cpu()))
                     self.debug_acts.append(rec)
-        return {task: L.to_nchw(feats[task]) for task in self.model_names}
+        out = {}
+        for task in self.model_names:
+            if streams[task] is not None:
+                with torch.cuda.stream(streams[task]):
+                    out[task] = L.to_nchw(feats[task])
+                main.wait_stream(streams[task])
+                out[task].record_stream(main)
+            else:
+                out[task] = L.to_nchw(feats[task])
+        return out
