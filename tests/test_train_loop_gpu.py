@@ -1,0 +1,89 @@
+"""-m gpu: the reference's train iteration (training_lit.py:82-87: training_step -> backward -> Adam.step)
+run for several steps.  Step k+1 only matches if the optimizer's in-place parameter update reached the
+packed GEMM operands (pack-cache invalidation through the parameter version / arena epoch), the BatchNorm
+running buffers and Adam's own state - none of which a single-step parity test exercises.
+Checker: the CPU oracle (oracle/mtan.py, pinned to the reference) driven by torch.optim.Adam."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+STEPS, LR = 4, 2e-3
+
+
+def _oracle_losses(fx, batch):
+    from oracle.losses import step_losses
+    from oracle.mtan import mtan_forward
+
+    sd = {k: v.clone() for k, v in fx["state_dict"].items()}
+    leaves = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    opt = torch.optim.Adam(leaves, lr=LR)
+    out = []
+    for _ in range(STEPS):
+        raw = mtan_forward(sd, batch["img"], list(dict(fx["tasks"])), fx["cfg"]["levels"], training=True)
+        loss = step_losses(raw, batch["mask"], batch["depth"])["loss"]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        out.append(float(loss.detach()))
+    return out
+
+
+def _model(fx, dev):
+    from vision_mtl_amd.models.mtan_model import MTANMiniUnet
+
+    c = fx["cfg"]
+    m = MTANMiniUnet(3, dict(fx["tasks"]), c["hidden"], c["first"], c["levels"])
+    m.load_state_dict(fx["state_dict"])
+    return m.to(dev).train()
+
+
+@pytest.mark.parametrize("mode", ["torch_adam", "arena_adam", "arena_adam_graph"])
+def test_training_loop_matches_oracle(dev, mode):
+    from vision_mtl_amd import dp
+    from vision_mtl_amd.lit_module import MTLModule
+
+    fx = torch.load(os.path.join(G, "mtan_tiny.pt"), weights_only=False)
+    ref = _oracle_losses(fx, fx["batch"])
+    assert ref[-1] < ref[0]  # the loop actually trains
+
+    model = _model(fx, dev)
+    module = MTLModule(model, num_classes=fx["cfg"]["C"], device=str(dev))
+    batch = {k: v.to(dev) for k, v in fx["batch"].items()}
+    got = []
+    if mode == "torch_adam":  # exactly run_pipe(): parameters are ordinary nn.Parameters
+        opt = torch.optim.Adam(module.parameters(), lr=LR)
+        for _ in range(STEPS):
+            loss = module.training_step(batch, 0)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            got.append(float(loss.detach()))
+    else:  # data-parallel form: flat arena, gradients written into slots, one fused Adam launch
+        arena = dp.FlatArena(model)
+        module.dp_arena = arena
+
+        def step():
+            loss = module.training_step(batch, 0)
+            loss.backward()
+            return loss.detach()
+
+        if mode == "arena_adam":
+            for _ in range(STEPS):
+                got.append(float(step()))
+                arena.adam_step(lr=LR)
+        else:  # fwd + bwd replayed from a hipGraph, optimizer between replays
+            got.append(float(step()))  # eager warm-up step (builds the packed-operand table)
+            arena.adam_step(lr=LR)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            # the capture itself does not execute: replay is step 2
+            for _ in range(STEPS - 1):
+                graph.replay()
+                got.append(float(static_loss))
+                arena.adam_step(lr=LR)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert abs(a - b) <= 2e-4 * abs(b), f"{mode}: step {k} loss {a} vs oracle {b}"
