@@ -84,7 +84,7 @@ def test_conv2d_fwd_bwd(dev, case):
         assert_close(bd.grad.cpu(), br.grad, what="conv bias grad")
 
 
-@pytest.mark.parametrize("tile", list(range(15)))
+@pytest.mark.parametrize("tile", list(range(16)))
 def test_conv2d_every_tile_config(dev, tile, monkeypatch):
     """Each implicit-GEMM tile configuration (ids in conv_igemm.hip, incl. the tail-column ones) forced
     through the tuning override on one ragged shape: values, pad zeros, BatchNorm partials, data gradient."""
@@ -193,7 +193,7 @@ def test_up2_conv(dev, case):
     _check_up2(dev, case)
 
 
-@pytest.mark.parametrize("tile", [0, 3, 5, 9, 12, 13, 14])
+@pytest.mark.parametrize("tile", [0, 3, 5, 9, 12, 13, 14, 15])
 def test_up2_conv_forced_tile(dev, tile, monkeypatch):
     monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
     _check_up2(dev, (2, 24, 6, 10, 12, 35))

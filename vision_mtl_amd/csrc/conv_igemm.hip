@@ -718,14 +718,16 @@ struct TileCfg { int bm, bn; float eff; };
 //  4 <4,3,2,2> 128x96    5 <4,4,2,2> 128x128   6 <2,9,4,1> 128x144   7 <4,5,2,2> 128x160
 //  8 <1,2,4,1> 64x32     9 <1,4,4,1> 64x64    10 <2,4,2,2> 64x128   11 <1,9,4,1> 64x144
 // 12 <2,2,4,1,+4> 128x(32+4)   13 <2,1,4,1,+4> 128x(16+4)   14 <2,4,4,1,+4> 128x(64+4)   (VALU tail columns)
+// 15 <2,1,4,1> 128x16
 // eff = measured MFMA-rate of the tile relative to the 144-wide one on MI355X (tools/bench_conv.py):
 // narrow tiles re-stage the A operand more often per MFMA.
-static const TileCfg kTiles[] = {{128, 32, 0.55f}, {128, 48, 0.72f}, {128, 64, 0.80f}, {128, 80, 0.88f},
+static const TileCfg kTiles[] = {{128, 32, 0.62f}, {128, 48, 0.72f}, {128, 64, 0.80f}, {128, 80, 0.88f},
                                  {128, 96, 0.92f}, {128, 128, 0.95f}, {128, 144, 1.0f}, {128, 160, 1.0f},
                                  {64, 32, 0.50f},  {64, 64, 0.85f},  {64, 128, 0.75f},  {64, 144, 1.0f},
-                                 {128, 36, 0.62f}, {128, 20, 0.43f}, {128, 68, 0.85f}};
-#define VMTL_NTILES 15
-static const int kBigIds[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14};
+                                 {128, 36, 0.62f}, {128, 20, 0.43f}, {128, 68, 0.85f}, {128, 16, 0.38f}};
+#define VMTL_NTILES 16
+#define VMTL_NBIG 12
+static const int kBigIds[] = {0, 1, 2, 3, 4, 5, 6, 7, 12, 13, 14, 15};
 static const int kSmallIds[] = {8, 9, 10, 11};
 
 static int pick_from(const int* ids, int n, int ncols) {
@@ -748,7 +750,7 @@ static int conv_pick_tile(int M, int ncols) {
     const int id = atoi(f);
     if (id >= 0 && id < VMTL_NTILES) return id;
   }
-  const int big = pick_from(kBigIds, 11, ncols);
+  const int big = pick_from(kBigIds, VMTL_NBIG, ncols);
   // too few workgroups for 256 CUs: halve the row block
   if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
   return big;
@@ -870,7 +872,8 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
     case 11: return launch_conv<1, 9, 4, 1>(p, st);
     case 12: return launch_conv<2, 2, 4, 1, false, 4>(p, st);
     case 13: return launch_conv<2, 1, 4, 1, false, 4>(p, st);
-    default: return launch_conv<2, 4, 4, 1, false, 4>(p, st);
+    case 14: return launch_conv<2, 4, 4, 1, false, 4>(p, st);
+    default: return launch_conv<2, 1, 4, 1>(p, st);
   }
 }
 
@@ -909,7 +912,8 @@ extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, flo
     case 11: rc = launch_conv<1, 9, 4, 1>(p, st); break;
     case 12: rc = launch_conv<2, 2, 4, 1, false, 4>(p, st); break;
     case 13: rc = launch_conv<2, 1, 4, 1, false, 4>(p, st); break;
-    default: rc = launch_conv<2, 4, 4, 1, false, 4>(p, st); break;
+    case 14: rc = launch_conv<2, 4, 4, 1, false, 4>(p, st); break;
+    default: rc = launch_conv<2, 1, 4, 1>(p, st); break;
   }
   if (rc) return rc;
   const long long n4 = (long long)p.M * ldy / 4;
@@ -930,7 +934,7 @@ static int up2_pick_tile(int Mq, int ncols) {
     const int id = atoi(f);
     if (id >= 0 && id < VMTL_NTILES) return id;
   }
-  const int big = pick_from(kBigIds, 11, ncols);
+  const int big = pick_from(kBigIds, VMTL_NBIG, ncols);
   if ((long long)cdiv(Mq, 128) * 4 * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
   return big;
 }
@@ -970,7 +974,8 @@ extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const flo
     case 11: return launch_conv<1, 9, 4, 1, true>(p, st);
     case 12: return launch_conv<2, 2, 4, 1, true, 4>(p, st);
     case 13: return launch_conv<2, 1, 4, 1, true, 4>(p, st);
-    default: return launch_conv<2, 4, 4, 1, true, 4>(p, st);
+    case 14: return launch_conv<2, 4, 4, 1, true, 4>(p, st);
+    default: return launch_conv<2, 1, 4, 1, true>(p, st);
   }
 }
 
