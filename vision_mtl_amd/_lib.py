@@ -55,12 +55,20 @@ def parse_header(path: Path = HEADER) -> dict:
 
 
 def build(force: bool = False) -> Path:
-    """Compile libvmtl.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    if force:
-        subprocess.run(["make", "-C", str(CSRC), "clean"], check=True, capture_output=True)
-    r = subprocess.run(["make", "-C", str(CSRC), "-j8"], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"building libvmtl.so failed:\n{r.stdout}\n{r.stderr}")
+    """Compile libvmtl.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  Serialised with a file
+    lock: the ranks of one node (one process per GPU) may all find the library missing at the same time."""
+    import fcntl
+
+    with open(CSRC / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force:
+                subprocess.run(["make", "-C", str(CSRC), "clean"], check=True, capture_output=True)
+            r = subprocess.run(["make", "-C", str(CSRC), "-j8"], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"building libvmtl.so failed:\n{r.stdout}\n{r.stderr}")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
