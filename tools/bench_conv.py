@@ -30,7 +30,9 @@ LAYERS = [("blk0.c1", 32, 8, 16, 1072, 540, 3), ("blk0.c2", 32, 8, 16, 540, 540,
           ("blk4.c1", 32, 128, 256, 67, 33, 3), ("blk4.c2", 32, 128, 256, 33, 33, 3),
           ("head20", 32, 128, 256, 33, 20, 3),
           # same GEMM shapes as blk2.c2 / blk3.c2 without tap re-reads (1x1): isolates the im2col operand traffic
-          ("pw.blk2c2", 32, 32, 64, 1215, 135, 1), ("pw.blk3c2", 32, 64, 128, 603, 67, 1)]
+          ("pw.blk2c2", 32, 32, 64, 1215, 135, 1), ("pw.blk3c2", 32, 64, 128, 603, 67, 1),
+          # MTAN attention 1x1 convs at full resolution (bs 16, 256x256): output-heavy, 4-6 K steps
+          ("pw.mtan192", 16, 256, 256, 128, 192, 1), ("pw.mtan128", 16, 256, 256, 192, 128, 1)]
 
 
 def timeit(fn):
