@@ -478,6 +478,37 @@ def test_squeeze_excite_fused(dev, case):
         assert_close(d[i].grad.cpu(), ref[i + 1].grad, what=f"se d{name}")
 
 
+@pytest.mark.parametrize("B", [3, 66])
+def test_squeeze_excite_module_both_paths(dev, B):
+    """The encoder's SqueezeExcite module: batch <= 64 takes the fused batch-sized-GEMM path, larger batches
+    the conv path (spatial mean -> 1x1 convs -> scale); both must equal the timm formula."""
+    from vision_mtl_amd import layers as L
+    from vision_mtl_amd.models.unet_mobilenetv3 import SqueezeExcite
+
+    ops = _ops()
+    assert (B <= ops.squeeze_excite_max_batch()) == (B == 3)
+    torch.manual_seed(31)
+    se = SqueezeExcite(40, 10)
+    x = torch.randn(B, 40, 4, 6)
+    xr = x.clone().requires_grad_(True)
+    s = F.conv2d(F.relu(F.conv2d(xr.mean((2, 3), keepdim=True), se.conv_reduce.weight, se.conv_reduce.bias)),
+                 se.conv_expand.weight, se.conv_expand.bias)
+    yr = xr * F.hardsigmoid(s)
+    gy = torch.randn(yr.shape)
+    yr.backward(gy)
+    ref_grads = [p.grad.clone() for p in se.parameters()]
+    for p in se.parameters():
+        p.grad = None
+    se = se.to(dev)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    y = se.run(L.Act(xd, 40))
+    assert_close(from_dev_nhwc(y.t, 40), yr.detach(), what="SE module fwd")
+    y.t.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, 40), xr.grad, what="SE module dx")
+    for p, g in zip(se.parameters(), ref_grads):
+        assert_close(p.grad.cpu(), g, what="SE module parameter gradient")
+
+
 @pytest.mark.parametrize("channel_wise", [True, False])
 def test_stitch(dev, channel_wise):
     ops = _ops()
