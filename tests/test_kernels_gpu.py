@@ -118,6 +118,35 @@ def test_conv2d_every_tile_config(dev, tile, monkeypatch):
     assert xd.grad[..., Cin:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("tile", [3, 4, 5, 6, 7, 10, 11])
+def test_conv2d_bf16x3_operand_split(dev, tile, monkeypatch):
+    """Opt-in VMTL_BF16X3=1: fp32 operands split exactly into three bf16 planes, six bf16 MFMAs per product.
+    Held to a TIGHTER bar than the fp32-MFMA path (2e-6 of the output magnitude): it is an fp32-accurate
+    formulation, not a reduced-precision one.  Forward values, BatchNorm partials, data gradient."""
+    ops = _ops()
+    monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
+    B, Cin, H, W, Cout = 2, 120, 17, 23, 150  # K = 9*120 = 1080: above the K >= 768 gate of the variant
+    g = torch.Generator().manual_seed(1900 + tile)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    yr = F.conv2d(x.double(), w.double(), None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VMTL_BF16X3", mode)
+        xd = to_dev_nhwc(x, dev).requires_grad_(True)
+        y, stats = ops.conv2d(xd, w.to(dev), None, stride=1, pad=1, want_stats=True)
+        y.backward(to_dev_nhwc(gy, dev))
+        out[mode] = (from_dev_nhwc(y, Cout).double(), from_dev_nhwc(xd.grad, Cin).double(), stats.cpu())
+    for mode, (y, dx, _) in out.items():
+        ey = float((y.detach() - yr).abs().max() / yr.abs().max())
+        ex = float((dx - dxr).abs().max() / dxr.abs().max())
+        assert ey < 2e-6 and ex < 2e-6, f"VMTL_BF16X3={mode}: fwd err {ey:.2e}, dgrad err {ex:.2e}"
+    assert not torch.equal(out["0"][0], out["1"][0])  # the switch really selected another kernel
+    assert_close(out["1"][2], out["0"][2], tol=1e-5, atol=1e-6, what="BatchNorm partials under bf16x3")
+
+
 @pytest.mark.parametrize("rows", [16, 32, 48, 64, 80, 144, 20, 36, 68])
 def test_conv2d_wgrad_every_row_config(dev, rows, monkeypatch):
     """Each weight-gradient tile height (incl. the VALU tail-row ones) forced through the tuning override."""

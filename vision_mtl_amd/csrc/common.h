@@ -24,6 +24,8 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Every launching entry point starts with VMTL_ENTER(): hipGetLastError() is per-thread state shared with
 // every other HIP user in the process (e.g. an ignored status inside the framework that hosts us), and

@@ -80,7 +80,28 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false, int NT = 0, int NS = 0>
+// X3 = 1 (opt-in, VMTL_BF16X3=1; NOT the default path): every fp32 operand is split EXACTLY into three bf16
+// values while it is staged (a = a1 + a2 + a3 by truncation, 8 significand bits each; LDS holds three
+// [row][32 bf16] planes per tile) and a product is formed from six v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, dropped terms < 2^-24 relative.  Measured error is
+// below the fp32-MFMA path's (tools/ubench/gemm_bf16x3_vs_f32.hip); see DESIGN.md section 7 for why it is
+// not switched on.
+__device__ __forceinline__ void split3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+  unsigned x[4], r1[4], r2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x[e] = __float_as_uint(v[e]);
+    const float f1 = v[e] - __uint_as_float(x[e] & 0xFFFF0000u);  // exact: the low 16 significand bits
+    r1[e] = __float_as_uint(f1);
+    const float f2 = f1 - __uint_as_float(r1[e] & 0xFFFF0000u);
+    r2[e] = __float_as_uint(f2);
+  }
+  p1 = (u32x2){__builtin_amdgcn_perm(x[1], x[0], 0x07060302u), __builtin_amdgcn_perm(x[3], x[2], 0x07060302u)};
+  p2 = (u32x2){__builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u)};
+  p3 = (u32x2){__builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u)};
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false, int NT = 0, int NS = 0, int X3 = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = WAVES_M * TM * 16;
   constexpr int BNM = WAVES_N * TN * 16;  // columns covered by MFMA tiles
@@ -92,6 +113,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   static_assert(NT == 0 || WAVES_N == 1, "tail columns need all waves to span the full tile width");
   static_assert(NS == 0 || (NS >= 2 && NS <= 4 && BM % 32 == 0), "LDS-DMA staging: 2..4 buffers, whole 32-row passes");
+  static_assert(X3 == 0 || (NS == 0 && NT == 0), "bf16x3 operands: register staging, no VALU tail columns");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [NBUF][BM][LDT]
@@ -203,7 +225,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     ci += BK;
     normalize();
   };
+  // X3 LDS image (bytes): A planes [2][3][BM][64], then B planes [2][3][BN][64]; the 16-byte slot s of row r
+  // sits at s ^ ((r >> 2) & 3) (rows r, r+4, r+8, r+12 of a fragment read would share a bank group otherwise)
+  unsigned char* A3 = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* B3 = A3 + 2 * 3 * BM * 64;
   auto store_tile = [&](int buf) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int row = r0 + 32 * i;
+        if (BM % 32 == 0 || row < BM) {
+          const int off = row * 64 + (((k4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((k4 & 1) << 3);
+          u32x2 p1, p2, p3;
+          split3(ra[i], p1, p2, p3);
+          *reinterpret_cast<u32x2*>(A3 + ((buf * 3 + 0) * BM) * 64 + off) = p1;
+          *reinterpret_cast<u32x2*>(A3 + ((buf * 3 + 1) * BM) * 64 + off) = p2;
+          *reinterpret_cast<u32x2*>(A3 + ((buf * 3 + 2) * BM) * 64 + off) = p3;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int row = r0 + 32 * i;
+        if (BN % 32 == 0 || row < BN) {
+          const int off = row * 64 + (((k4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((k4 & 1) << 3);
+          u32x2 p1, p2, p3;
+          split3(rb[i], p1, p2, p3);
+          *reinterpret_cast<u32x2*>(B3 + ((buf * 3 + 0) * BN) * 64 + off) = p1;
+          *reinterpret_cast<u32x2*>(B3 + ((buf * 3 + 1) * BN) * 64 + off) = p2;
+          *reinterpret_cast<u32x2*>(B3 + ((buf * 3 + 2) * BN) * 64 + off) = p3;
+        }
+      }
+      return;
+    }
     float* a = As + buf * BM * LDT;
     float* b = Bs + buf * BNR * LDT;
     const int ks = (k4 ^ (r0 & 7)) * 4;  // (r0 + 32 i) & 7 == r0 & 7
@@ -238,6 +291,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
   // one BK chunk of MFMAs (+ VALU tail columns) on staging buffer `cur`
   auto compute = [&](int cur) {
+    if constexpr (X3) {
+      // lane (l15, lq) holds k = 8*lq .. 8*lq+7 of its row: the 16-byte slot lq of each plane
+      bf16x8 fa[TM][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 16 + l15;
+        const int off = row * 64 + ((lq ^ ((row >> 2) & 3)) << 4);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) fa[i][s3] = *reinterpret_cast<const bf16x8*>(A3 + ((cur * 3 + s3) * BM) * 64 + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 16 + l15;
+        const int off = row * 64 + ((lq ^ ((row >> 2) & 3)) << 4);
+        bf16x8 fb[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) fb[s3] = *reinterpret_cast<const bf16x8*>(B3 + ((cur * 3 + s3) * BN) * 64 + off);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f32x4 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][2], fb[0], c, 0, 0, 0);  // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][1], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][0], fb[0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      }
+      return;
+    }
     // fragment rows are (tile base + l15) with tile bases multiples of 16: row & 7 == l15 & 7
     const float* a = As + cur * BM * LDT + (wm * TM * 16 + l15) * LDT;
     const float* b = Bs + cur * BNR * LDT + (wn * TN * 16 + l15) * LDT;
@@ -765,8 +849,14 @@ extern "C" int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy) {
   return kTiles[conv_pick_tile(B * Ho * Wo, ldy)].bm;
 }
 
-template <int TM, int TN, int WMV, int WNV, bool UP2, int NT, int NS>
+template <int TM, int TN, int WMV, int WNV, bool UP2, int NT, int NS, int X3 = 0>
 static int launch_conv_ns(ConvP& p, hipStream_t st);
+
+// opt-in bf16x3 operand split for the wide tiles (VMTL_BF16X3=1); see the kernel comment
+static bool conv_bf16x3() {
+  const char* e = getenv("VMTL_BF16X3");  // read per call: the parity tests toggle it
+  return e && atoi(e) == 1;
+}
 
 // LDS-DMA staging depth: 0 = register staging.  VMTL_GLDS overrides (tuning aid).
 static int conv_glds_stages() {
@@ -781,6 +871,11 @@ static int conv_glds_stages() {
 
 template <int TM, int TN, int WMV, int WNV, bool UP2 = false, int NT = 0>
 static int launch_conv(ConvP& p, hipStream_t st) {
+  if constexpr (NT == 0 && WNV * TN >= 5) {
+    // long K loops only: the three planes need 1.5x the LDS (one workgroup per CU for the 128-row tiles), which a
+    // 4-6 step loop cannot amortise (MTAN's full-resolution 1x1 convs ran 40 % slower with it)
+    if (conv_bf16x3() && cdiv(p.Ktot, BK) >= 24) return launch_conv_ns<TM, TN, WMV, WNV, UP2, NT, 0, 1>(p, st);
+  }
   if constexpr (!UP2 && (WMV * TM) % 2 == 0) {
     const int ns = conv_glds_stages();
     if (ns == 2) return launch_conv_ns<TM, TN, WMV, WNV, UP2, NT, 2>(p, st);
@@ -789,7 +884,7 @@ static int launch_conv(ConvP& p, hipStream_t st) {
   return launch_conv_ns<TM, TN, WMV, WNV, UP2, NT, 0>(p, st);
 }
 
-template <int TM, int TN, int WMV, int WNV, bool UP2, int NT, int NS>
+template <int TM, int TN, int WMV, int WNV, bool UP2, int NT, int NS, int X3>
 static int launch_conv_ns(ConvP& p, hipStream_t st) {
   constexpr int BM = WMV * TM * 16, BN = WNV * TN * 16 + NT;
   p.tiles_m = cdiv(p.M, BM) * (UP2 ? 4 : 1);
@@ -800,14 +895,14 @@ static int launch_conv_ns(ConvP& p, hipStream_t st) {
     return VMTL_ERR_UNSUPPORTED;
   constexpr int NBUF = NS >= 2 ? NS : 2;
   constexpr int BNR = NS >= 2 ? (BN + 31) / 32 * 32 : BN;
-  const size_t lds = (size_t)NBUF * (BM + BNR) * LDT * sizeof(float);
+  const size_t lds = X3 ? (size_t)2 * 3 * (BM + BN) * 64 : (size_t)NBUF * (BM + BNR) * LDT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT, NS, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT, NS>),
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WMV, WNV, UP2, NT, NS, X3>),
                      dim3(p.tiles_m * p.tiles_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
