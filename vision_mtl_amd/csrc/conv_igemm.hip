@@ -829,6 +829,8 @@ static int pick_from(const int* ids, int n, int ncols) {
   return best;
 }
 
+static bool conv_bf16x3();
+
 static int conv_pick_tile(int M, int ncols) {
   if (const char* f = getenv("VMTL_FORCE_TILE")) {  // tuning aid (tools/bench_conv.py), never set in production
     const int id = atoi(f);
@@ -837,6 +839,9 @@ static int conv_pick_tile(int M, int ncols) {
   const int big = pick_from(kBigIds, VMTL_NBIG, ncols);
   // too few workgroups for 256 CUs: halve the row block
   if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
+  // opt-in bf16x3 operands need 1.5x the LDS: only the 64-row tiles keep two workgroups per CU
+  // (measured: 65536 x 135 x 1215 at 164 us with 64x144 against 198 us with 128x144)
+  if (conv_bf16x3() && kTiles[big].bn >= 80) return pick_from(kSmallIds, 4, ncols);
   return big;
 }
 
@@ -1031,6 +1036,7 @@ static int up2_pick_tile(int Mq, int ncols) {
   }
   const int big = pick_from(kBigIds, VMTL_NBIG, ncols);
   if ((long long)cdiv(Mq, 128) * 4 * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
+  if (conv_bf16x3() && kTiles[big].bn >= 80) return pick_from(kSmallIds, 4, ncols);
   return big;
 }
 
