@@ -13,13 +13,19 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 STEPS, LR = 4, 2e-3
 
 
-def _oracle_losses(fx, batch):
+def _scheduler(opt):
+    # the reference's scheduler class with a trigger-happy setting so that 4 steps exercise it
+    return torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", patience=0, factor=0.5)
+
+
+def _oracle_losses(fx, batch, scheduled=False):
     from oracle.losses import step_losses
     from oracle.mtan import mtan_forward
 
     sd = {k: v.clone() for k, v in fx["state_dict"].items()}
     leaves = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k]
     opt = torch.optim.Adam(leaves, lr=LR)
+    sched = _scheduler(opt) if scheduled else None
     out = []
     for _ in range(STEPS):
         raw = mtan_forward(sd, batch["img"], list(dict(fx["tasks"])), fx["cfg"]["levels"], training=True)
@@ -27,6 +33,8 @@ def _oracle_losses(fx, batch):
         opt.zero_grad()
         loss.backward()
         opt.step()
+        if sched is not None:
+            sched.step(float(loss.detach()))  # mode="max" on a falling loss: the rate halves every step
         out.append(float(loss.detach()))
     return out
 
@@ -40,13 +48,13 @@ def _model(fx, dev):
     return m.to(dev).train()
 
 
-@pytest.mark.parametrize("mode", ["torch_adam", "arena_adam", "arena_adam_graph"])
+@pytest.mark.parametrize("mode", ["torch_adam", "arena_adam", "arena_adam_graph", "arena_optimizer_scheduler"])
 def test_training_loop_matches_oracle(dev, mode):
     from vision_mtl_amd import dp
     from vision_mtl_amd.lit_module import MTLModule
 
     fx = torch.load(os.path.join(G, "mtan_tiny.pt"), weights_only=False)
-    ref = _oracle_losses(fx, fx["batch"])
+    ref = _oracle_losses(fx, fx["batch"], scheduled=mode == "arena_optimizer_scheduler")
     assert ref[-1] < ref[0]  # the loop actually trains
 
     model = _model(fx, dev)
@@ -74,6 +82,23 @@ def test_training_loop_matches_oracle(dev, mode):
             for _ in range(STEPS):
                 got.append(float(step()))
                 arena.adam_step(lr=LR)
+        elif mode == "arena_optimizer_scheduler":  # dp.ArenaAdam behind torch's scheduler + state_dict round trip
+            opt = dp.ArenaAdam(arena, lr=LR)
+            sched = _scheduler(opt)
+            for k in range(STEPS):
+                loss = step()
+                opt.zero_grad()
+                opt.step()
+                sched.step(float(loss))
+                got.append(float(loss))
+                if k == 1:  # checkpoint / restore in the middle of the run
+                    sd = opt.state_dict()
+                    opt = dp.ArenaAdam(arena, lr=123.0)
+                    opt.load_state_dict(sd)
+                    sched2 = _scheduler(opt)
+                    sched2.load_state_dict(sched.state_dict())
+                    sched = sched2
+            assert opt.param_groups[0]["lr"] < LR
         else:  # fwd + bwd replayed from a hipGraph, optimizer between replays
             got.append(float(step()))  # eager warm-up step (builds the packed-operand table)
             arena.adam_step(lr=LR)

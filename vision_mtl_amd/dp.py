@@ -80,6 +80,39 @@ class FlatArena:
         ops.packs.invalidate()  # parameters changed through raw pointers: packed operands are stale
 
 
+class ArenaAdam(torch.optim.Optimizer):
+    """torch.optim.Adam's interface over FlatArena.adam_step (one fused launch over the flat buffers):
+    `param_groups`, `state_dict` / `load_state_dict` and `zero_grad` behave like an optimizer's, so the
+    reference's scheduler (`ReduceLROnPlateau`, training_lit.py:51-55) and checkpoint writer
+    (`save_ckpt`, pipeline_utils.py:139-167) drive the arena path unchanged."""
+
+    def __init__(self, arena: "FlatArena", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.arena = arena
+        super().__init__([arena.flat_param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        self.arena.adam_step(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+        return loss
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Nothing to clear: every backward pass overwrites the gradient slots (it never accumulates)."""
+
+    def state_dict(self):
+        st = self.arena._adam
+        return {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "arena": None if st is None else {k: v.clone() for k, v in st.items()}}
+
+    def load_state_dict(self, sd):
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update(saved)
+        if sd.get("arena") is not None:
+            dev = self.arena.flat_param.device
+            self.arena._adam = {k: v.to(dev).clone() for k, v in sd["arena"].items()}
+
+
 class _SyncGrads(torch.autograd.Function):
     """Identity on the loss; its backward (the first node the engine runs) queues FlatArena._end_of_backward."""
 
