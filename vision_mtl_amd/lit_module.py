@@ -129,11 +129,16 @@ class MTLModule(nn.Module):
                 "lr_scheduler": {"scheduler": scheduler, "interval": "epoch", "monitor": "train_loss"}}
 
     def transfer_batch_to_device(self, batch: dict, device, dataloader_idx: int = 0):
+        # pinned host tensors (DataLoader(pin_memory=True)) go up asynchronously on the current stream; the model
+        # re-lays the NCHW image to its NHWC storage format on the device (vmtl_nchw_to_nhwc)
+        def up(t):
+            return t.to(device, non_blocking=t.device.type == "cpu" and t.is_pinned())
+
         if isinstance(batch, dict):
             for key in batch.keys():
-                batch[key] = batch[key].to(device)
+                batch[key] = up(batch[key])
             return batch
-        return batch.to(device)
+        return up(batch)
 
     def parameters(self, recurse: bool = True):  # reference lit_module.py:232-234
         for p in self.model.parameters():
