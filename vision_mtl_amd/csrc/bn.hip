@@ -374,25 +374,30 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mul, float* __restrict__ dmul, int M, int C, int Cs, float* partial) {
   const int CQ = Cs >> 2;
-  column_reduce_init<2>(
+  struct Row { f32x4 xv, g, mv; };
+  column_reduce_init2<2>(
       M, CQ, Cs, partial, [&](int q) { return bn_bwd_coef(q, C, mean, invstd, gamma, beta, nullptr, nullptr, 0.f); },
-      [&](int r, int q, const BnBwdCoef& k, f32x4* acc) {
+      [&](int r, int q) {
         const size_t off = (size_t)r * Cs + (size_t)q * 4;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
-        f32x4 mv = {1.f, 1.f, 1.f, 1.f};
-        if (mul != nullptr) mv = *reinterpret_cast<const f32x4*>(mul + off);
-        const f32x4 xh = (xv - k.mean) * k.invstd;
+        Row l;
+        l.xv = *reinterpret_cast<const f32x4*>(x + off);
+        l.g = *reinterpret_cast<const f32x4*>(dy + off);
+        l.mv = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (mul != nullptr) l.mv = *reinterpret_cast<const f32x4*>(mul + off);
+        return l;
+      },
+      [&](const Row& l, int r, int q, const BnBwdCoef& k, f32x4* acc) {
+        const f32x4 xh = (l.xv - k.mean) * k.invstd;
         const f32x4 z = k.gamma * xh + k.beta;
         f32x4 dm, dz;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          dm[e] = k.valid[e] * g[e] * act_fwd(z[e], ACT);
-          dz[e] = k.valid[e] * g[e] * mv[e] * act_grad(z[e], ACT);
+          dm[e] = k.valid[e] * l.g[e] * act_fwd(z[e], ACT);
+          dz[e] = k.valid[e] * l.g[e] * l.mv[e] * act_grad(z[e], ACT);
         }
         acc[0] += dz;
         acc[1] += dz * xh;
-        if (dmul != nullptr) *reinterpret_cast<f32x4*>(dmul + off) = dm;
+        if (dmul != nullptr) *reinterpret_cast<f32x4*>(dmul + (size_t)r * Cs + (size_t)q * 4) = dm;
       });
 }
 

@@ -77,6 +77,53 @@ __device__ __forceinline__ void column_reduce_init(int M, int CQ, int Cs, float*
   }
 }
 
+// column_reduce_init with the row loop split into LOAD and ACCUMULATE so that two rows' loads are issued before
+// either row's arithmetic (the plain form has one row = 2-3 loads in flight per thread; these sweeps are
+// latency-bound at 4 workgroups per CU)
+template <int K, typename Init, typename Load, typename Accum>
+__device__ __forceinline__ void column_reduce_init2(int M, int CQ, int Cs, float* partial, Init init, Load load, Accum accum) {
+  __shared__ f32x4 red[RED_THREADS];
+  const int nblk = gridDim.x;
+  const int rows_per_blk = (M + nblk - 1) / nblk;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int T = rpt * cq;
+    const int t = threadIdx.x;
+    const int q = q0 + t % cq, ro = t / cq;
+    f32x4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+      auto st = init(q);
+      int r = r_begin + ro;
+      for (; r + rpt < r_end; r += 2 * rpt) {
+        auto l0 = load(r, q);
+        auto l1 = load(r + rpt, q);
+        accum(l0, r, q, st, acc);
+        accum(l1, r + rpt, q, st, acc);
+      }
+      if (r < r_end) {
+        auto l0 = load(r, q);
+        accum(l0, r, q, st, acc);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      __syncthreads();
+      red[t] = acc[k];
+      __syncthreads();
+      if (t < cq) {
+        f32x4 s = red[t];
+        for (int j = 1; j < rpt; ++j) s += red[t + j * cq];
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * K + k) * Cs + (size_t)(q0 + t) * 4) = s;
+      }
+    }
+  }
+}
+
 static inline int red_blocks(int M) {
   int nb = cdiv(M, 16);  // small maps with many channels still get a few hundred workgroups
   if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
