@@ -198,17 +198,26 @@ __global__ __launch_bounds__(RED_THREADS) void bn_apply_kernel(const float* __re
                                                                const float* __restrict__ mul,
                                                                const float* __restrict__ res, float* __restrict__ y,
                                                                int M, int C, int Cs) {
-  column_sweep(
+  struct Row { f32x4 v, m, r; };
+  column_sweep2(
       M, Cs >> 2, [&](int q) { return bn_coef(q, C, mean, invstd, gamma, beta); },
-      [&](int r, int q, const BnCoef& k) {
+      [&](int r, int q) {
         const size_t off = (size_t)r * Cs + (size_t)q * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+        Row l;
+        l.v = *reinterpret_cast<const f32x4*>(x + off);
+        l.m = (f32x4){1.f, 1.f, 1.f, 1.f};
+        l.r = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (mul != nullptr) l.m = *reinterpret_cast<const f32x4*>(mul + off);
+        if (res != nullptr) l.r = *reinterpret_cast<const f32x4*>(res + off);
+        return l;
+      },
+      [&](const Row& l, int r, int q, const BnCoef& k) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = k.valid[e] != 0.f ? act_fwd(v[e] * k.sc[e] + k.sh[e], ACT) : 0.f;
-        if (mul != nullptr) o *= *reinterpret_cast<const f32x4*>(mul + off);
-        if (res != nullptr) o += *reinterpret_cast<const f32x4*>(res + off);
-        *reinterpret_cast<f32x4*>(y + off) = o;
+        for (int e = 0; e < 4; ++e) o[e] = k.valid[e] != 0.f ? act_fwd(l.v[e] * k.sc[e] + k.sh[e], ACT) : 0.f;
+        if (mul != nullptr) o *= l.m;
+        if (res != nullptr) o += l.r;
+        *reinterpret_cast<f32x4*>(y + (size_t)r * Cs + (size_t)q * 4) = o;
       });
 }
 
@@ -423,25 +432,30 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_apply_kernel(
     float* __restrict__ dx, int M, int C, int Cs, int training) {
   const float invM = 1.f / (float)M;
   const bool use_sums = training && mean != nullptr;
-  column_sweep(
+  struct Row { f32x4 xv, g, mv; };
+  column_sweep2(
       M, Cs >> 2,
       [&](int q) {
         return bn_bwd_coef(q, C, mean, invstd, gamma, beta, use_sums ? sum_dz : nullptr, use_sums ? sum_dzx : nullptr,
                            invM);
       },
-      [&](int r, int q, const BnBwdCoef& k) {
+      [&](int r, int q) {
         const size_t off = (size_t)r * Cs + (size_t)q * 4;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
-        f32x4 mv = {1.f, 1.f, 1.f, 1.f};
-        if (mul != nullptr) mv = *reinterpret_cast<const f32x4*>(mul + off);
-        const f32x4 xh = (xv - k.mean) * k.invstd;
+        Row l;
+        l.xv = *reinterpret_cast<const f32x4*>(x + off);
+        l.g = *reinterpret_cast<const f32x4*>(dy + off);
+        l.mv = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (mul != nullptr) l.mv = *reinterpret_cast<const f32x4*>(mul + off);
+        return l;
+      },
+      [&](const Row& l, int r, int q, const BnBwdCoef& k) {
+        const f32x4 xh = (l.xv - k.mean) * k.invstd;
         const f32x4 z = k.gamma * xh + k.beta;
         f32x4 dz;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dz[e] = k.valid[e] * g[e] * mv[e] * act_grad(z[e], ACT);
+        for (int e = 0; e < 4; ++e) dz[e] = k.valid[e] * l.g[e] * l.mv[e] * act_grad(z[e], ACT);
         // without BatchNorm (mean == nullptr) gamma = invstd = 1 and c1 = c2 = 0: dx = dz
-        *reinterpret_cast<f32x4*>(dx + off) = k.gamma * k.invstd * (dz - k.c1 - xh * k.c2);
+        *reinterpret_cast<f32x4*>(dx + (size_t)r * Cs + (size_t)q * 4) = k.gamma * k.invstd * (dz - k.c1 - xh * k.c2);
       });
 }
 

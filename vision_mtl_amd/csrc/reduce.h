@@ -181,6 +181,34 @@ __device__ __forceinline__ void column_sweep(int M, int CQ, Init init, Body body
   }
 }
 
+// column_sweep with LOAD and BODY split: two rows' loads are issued before either row's arithmetic / store
+template <typename Init, typename Load, typename Body>
+__device__ __forceinline__ void column_sweep2(int M, int CQ, Init init, Load load, Body body) {
+  const int nblk = gridDim.x;
+  const int rows_per_blk = (M + nblk - 1) / nblk;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int t = threadIdx.x;
+    if (t >= rpt * cq) continue;
+    const int q = q0 + t % cq, ro = t / cq;
+    auto st = init(q);
+    int r = r_begin + ro;
+    for (; r + rpt < r_end; r += 2 * rpt) {
+      auto l0 = load(r, q);
+      auto l1 = load(r + rpt, q);
+      body(l0, r, q, st);
+      body(l1, r + rpt, q, st);
+    }
+    if (r < r_end) {
+      auto l0 = load(r, q);
+      body(l0, r, q, st);
+    }
+  }
+}
+
 static inline int sweep_blocks(long long M, int Cs) {
   // ~16 float4 per thread per block keeps enough loads in flight without starving the grid
   long long per_blk = (long long)RED_THREADS * 16 / (Cs >> 2 > 0 ? (Cs >> 2) : 1);
