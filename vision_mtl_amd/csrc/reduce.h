@@ -5,6 +5,9 @@
 
 #define RED_THREADS 256
 #define RED_MAX_BLOCKS 1024
+#ifndef VMTL_RIF
+#define VMTL_RIF 2  // rows whose loads are in flight per thread in the split load/accumulate sweeps
+#endif
 
 // Column reduction skeleton.  The [M][CQ] float4 matrix is swept by T = (256/CQ)*CQ
 // threads so that a thread keeps ONE float4 column (q fixed) while stepping rows;
@@ -99,13 +102,14 @@ __device__ __forceinline__ void column_reduce_init2(int M, int CQ, int Cs, float
     if (t < T) {
       auto st = init(q);
       int r = r_begin + ro;
-      for (; r + rpt < r_end; r += 2 * rpt) {
-        auto l0 = load(r, q);
-        auto l1 = load(r + rpt, q);
-        accum(l0, r, q, st, acc);
-        accum(l1, r + rpt, q, st, acc);
+      for (; r + (VMTL_RIF - 1) * rpt < r_end; r += VMTL_RIF * rpt) {
+        decltype(load(r, q)) l[VMTL_RIF];
+#pragma unroll
+        for (int u = 0; u < VMTL_RIF; ++u) l[u] = load(r + u * rpt, q);
+#pragma unroll
+        for (int u = 0; u < VMTL_RIF; ++u) accum(l[u], r + u * rpt, q, st, acc);
       }
-      if (r < r_end) {
+      for (; r < r_end; r += rpt) {
         auto l0 = load(r, q);
         accum(l0, r, q, st, acc);
       }
@@ -196,13 +200,14 @@ __device__ __forceinline__ void column_sweep2(int M, int CQ, Init init, Load loa
     const int q = q0 + t % cq, ro = t / cq;
     auto st = init(q);
     int r = r_begin + ro;
-    for (; r + rpt < r_end; r += 2 * rpt) {
-      auto l0 = load(r, q);
-      auto l1 = load(r + rpt, q);
-      body(l0, r, q, st);
-      body(l1, r + rpt, q, st);
+    for (; r + (VMTL_RIF - 1) * rpt < r_end; r += VMTL_RIF * rpt) {
+      decltype(load(r, q)) l[VMTL_RIF];
+#pragma unroll
+      for (int u = 0; u < VMTL_RIF; ++u) l[u] = load(r + u * rpt, q);
+#pragma unroll
+      for (int u = 0; u < VMTL_RIF; ++u) body(l[u], r + u * rpt, q, st);
     }
-    if (r < r_end) {
+    for (; r < r_end; r += rpt) {
       auto l0 = load(r, q);
       body(l0, r, q, st);
     }
