@@ -87,10 +87,13 @@ def time_conv_kernels(module, batch, reps=3):
         f["xflop"] = f.get("xflop", 0.0) + xflop
         f["ms"] += ms
         f["launches"] += 1
-        if os.environ.get("VMTL_CONV_TABLE") and "Ho" in kw:
-            M = kw["B"] * kw["Ho"] * kw["Wo"]
-            log(f"{name[12:]:6s} M={M:8d} N={kw['Nw']:5d} K={kw['KH'] * kw['KW'] * kw['Cs']:6d} "
-                f"k{kw['KH']}s{kw['stride']} {ms * 1e3:9.1f} us {flop / ms / 1e9:7.1f} TF (executed {xflop / ms / 1e9:6.1f})")
+        if os.environ.get("VMTL_CONV_TABLE"):
+            if "Ho" in kw:
+                M, K, tag = kw["B"] * kw["Ho"] * kw["Wo"], kw["KH"] * kw["KW"] * kw["Cs"], f"k{kw['KH']}s{kw['stride']}"
+            else:
+                M, K, tag = kw["B"] * kw["H"] * kw["W"], 9 * kw.get("Cs", 0), "k3s1" if "ep_mode" in kw else "up2 "
+            log(f"{name[5:]:14s} M={M:8d} N={kw.get('Nw', kw.get('Cout', 0)):5d} K={K:6d} {tag} {ms * 1e3:9.1f} us "
+                f"{flop / ms / 1e9:7.1f} TF (executed {xflop / ms / 1e9:6.1f})")
     return fam
 
 

@@ -73,6 +73,26 @@ int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot);
 int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits, int B, int H, int W, int Cs,
                       int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad, void* stream);
 
+/* 3x3 / stride 1 / pad 1 conv for the narrow full-resolution layers (Cs in {16,20,32,36} storage channels in,
+ * Nw <= 36 rows of the packed [Nw][9*Cs] weight out): the last decoder block and the heads of `basic`
+ * (models/basic_model.py:30-51; smp DecoderBlock conv2 via utils/model_utils.py:25-34) and their data gradients.
+ * Halo tile in LDS, weights resident in LDS, persistent workgroups (csrc/conv_small.hip).
+ *   prologue: v = act_in(pa[c]*x + pb[c]*x2 + pc[c]) once per input element (pa null: identity; x2/pb null:
+ *             one operand); a_out (optional, needs pa) receives the transformed input.
+ *   ep_mode 0: y = conv + bias.  yb != null: NCHW split store, channels [0,Ca) -> y [B][Ca][H][W], the rest -> yb.
+ *   ep_mode 1: y = conv, stats[tile][2][ldy] = per-tile (mean, M2) of y (tiles of 128 pixels, vmtl_conv3x3_small_tiles).
+ *   ep_mode 2: y = conv * act'(z), z = ez_gamma*xhat + ez_beta, xhat = (ez_x - ez_mean)*ez_invstd (BatchNorm + activation
+ *              backward of the layer that produced the tensor whose gradient this conv computes);
+ *              stats[tile][2][ldy] = per-tile (sum y, sum y*xhat).
+ * ep_mode 1/2 need H % 4 == 0 and W % 32 == 0. */
+int vmtl_conv3x3_small_supported(int Cs, int Nw);
+int vmtl_conv3x3_small_tiles(int B, int H, int W);
+int vmtl_conv3x3_small(const float* x, const float* x2, const float* pa, const float* pb, const float* pc,
+                       int act_in, float* a_out, const float* wp, const float* bias, float* y, float* yb, int Ca,
+                       float* stats, int ep_mode, const float* ez_x, const float* ez_mean, const float* ez_invstd,
+                       const float* ez_gamma, const float* ez_beta, int ez_act, int B, int H, int W, int Cs, int ldy,
+                       int Nw, int Cout, void* stream);
+
 /* depthwise KxK (K in {3,5}, stride in {1,2}); wp is packed [K*K][Cs]. */
 int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B, int H, int W, int Cs, int Ho, int Wo,
                     int K, int stride, int pad, void* stream);
@@ -103,6 +123,15 @@ int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk
                   float* save_mean, float* save_invstd, void* stream);
 int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int C, int Cs, float eps,
                        float* save_mean, float* save_invstd, void* stream);
+/* the same two, additionally emitting the normalisation as per-channel prologue coefficients of the consumer
+ * conv (vmtl_conv3x3_small): act(BN(x)) = act(coef_a[c] * x + coef_c[c]), zeros on the pad channels */
+int vmtl_bn_stats_coef(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
+                       int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var,
+                       long long* num_batches_tracked, float* save_mean, float* save_invstd, const float* gamma,
+                       const float* beta, float* coef_a, float* coef_c, void* stream);
+int vmtl_bn_eval_stats_coef(const float* running_mean, const float* running_var, int C, int Cs, float eps,
+                            float* save_mean, float* save_invstd, const float* gamma, const float* beta,
+                            float* coef_a, float* coef_c, void* stream);
 int vmtl_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, const float* mul, const float* res, float* y, long long M, int C,
                   int Cs, int act, void* stream);
@@ -116,6 +145,15 @@ int vmtl_bn_apply_fused(const float* x, const float* partial, int nblk, int rows
 int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                 const float* beta, const float* mul, float* dmul, float* partial, float* sum_dz,
                 float* sum_dzx, float* dx, int M, int C, int Cs, int act, int training, void* stream);
+/* vmtl_bn_bwd in two halves, for producers whose epilogue already emitted dz = dy * act'(z) and the per-block
+ * column sums rows [nblk][2][Cs] = (sum dz, sum dz*xhat): finalize -> BatchNorm parameter gradients (+ optional
+ * coefficients of dx = coef_a*dz + coef_b*x + coef_c for a consumer that applies it while loading); apply -> dx. */
+int vmtl_bn_bwd_finalize(const float* partial, int nblk, int M, int C, int Cs, float* sum_dz, float* sum_dzx,
+                         const float* mean, const float* invstd, const float* gamma, int training, float* coef_a,
+                         float* coef_b, float* coef_c, void* stream);
+int vmtl_bn_bwd_apply(const float* x, const float* dz, const float* mean, const float* invstd, const float* gamma,
+                      const float* sum_dz, const float* sum_dzx, float* dx, int M, int C, int Cs, int training,
+                      void* stream);
 /* out[c] = sum_m a[m][c] (mode 0) or a*b (mode 1); reduce_all sums over channels too. */
 int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
                 float* partial, float* out, void* stream);

@@ -1,0 +1,171 @@
+"""-m gpu: the halo-tile 3x3 kernel for the narrow full-resolution layers (csrc/conv_small.hip) and the fused
+decoder tail built on it (ops.decoder_tail), against plain PyTorch fp32 on the CPU.  The reference composition is
+smp DecoderBlock.conv2 (Conv-BN-ReLU) + the two 3x3 heads of reference vision_mtl/models/basic_model.py:30-51.
+Tolerance 1e-4 of the reference's max magnitude (BASELINE.json north_star)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close, ceil4, from_dev_nhwc, to_dev_nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(ops, x, wp, y, Cs, ldy, Nw, Cout, **kw):
+    B, H, W, _ = x.shape
+    ops._small(x, wp, y, B, H, W, Cs, ldy, Nw, Cout, 0.0, **kw)
+
+
+def _pack_fwd(ops, w, dev):
+    Cout, Cin = w.shape[:2]
+    return ops.pack(w.to(dev), 1, Cout, 9, Cin, ceil4(Cin), 0, Cin * 9, 1, 9)
+
+
+# B, Cin, Cout, H, W
+SMALL_CASES = [(2, 33, 33, 8, 64), (1, 33, 20, 12, 32), (2, 20, 33, 4, 96), (1, 32, 32, 8, 32), (2, 16, 14, 8, 32),
+               (1, 33, 33, 7, 45)]  # the last one: partial tiles (plain mode only)
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_conv3x3_small_plain_and_prologue(dev, case):
+    from vision_mtl_amd import ops
+
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    Cs, ldy = ceil4(Cin), ceil4(Cout)
+    xd, wp = to_dev_nhwc(x, dev), _pack_fwd(ops, w, dev)
+    # plain + bias
+    y = torch.full((B, H, W, ldy), float("nan"), device=dev)
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, bias=bias.to(dev))
+    assert_close(from_dev_nhwc(y, Cout), F.conv2d(x, w, bias, padding=1), what="small conv plain")
+    assert float(y[..., Cout:].abs().sum()) == 0.0, "pad channels must be zero"
+    # prologue relu(a*x + c), transformed input written back
+    pa, pc = torch.randn(Cin, generator=g), torch.randn(Cin, generator=g)
+    pad = lambda v: torch.cat([v, torch.zeros(Cs - Cin)]).to(dev)
+    a_out = torch.full_like(xd, float("nan"))
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, pa=pad(pa), pc=pad(pc), act_in=ops.ACT_RELU, a_out=a_out)
+    a_ref = F.relu(x * pa.view(1, -1, 1, 1) + pc.view(1, -1, 1, 1))
+    assert_close(from_dev_nhwc(a_out, Cin), a_ref, what="small conv a_out")
+    assert float(a_out[..., Cin:].abs().sum()) == 0.0
+    assert_close(from_dev_nhwc(y, Cout), F.conv2d(a_ref, w, None, padding=1), what="small conv prologue")
+    # two-operand affine prologue, no activation
+    x2 = torch.randn(B, Cin, H, W, generator=g)
+    pb = torch.randn(Cin, generator=g)
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, x2=to_dev_nhwc(x2, dev), pa=pad(pa), pb=pad(pb), pc=pad(pc), a_out=a_out)
+    v = lambda t: t.view(1, -1, 1, 1)
+    a_ref = x * v(pa) + x2 * v(pb) + v(pc)
+    assert_close(from_dev_nhwc(a_out, Cin), a_ref, what="small conv 2-operand a_out")
+    assert_close(from_dev_nhwc(y, Cout), F.conv2d(a_ref, w, None, padding=1), what="small conv 2-operand prologue")
+
+
+@pytest.mark.parametrize("case", SMALL_CASES[:5])
+def test_conv3x3_small_epilogues(dev, case):
+    from vision_mtl_amd import ops
+    from vision_mtl_amd._lib import lib
+
+    B, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    Cs, ldy = ceil4(Cin), ceil4(Cout)
+    xd, wp = to_dev_nhwc(x, dev), _pack_fwd(ops, w, dev)
+    yr = F.conv2d(x, w, None, padding=1)
+    tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
+    assert tiles == B * (H // 4) * (W // 32)
+
+    def per_tile(t):  # (B,C,H,W) -> (tiles, C, 128) in the kernel's tile order (image, tile row, tile column)
+        return t.view(B, -1, H // 4, 4, W // 32, 32).permute(0, 2, 4, 1, 3, 5).reshape(tiles, t.shape[1], 128)
+
+    # mode 1: per-tile (mean, M2)
+    y = torch.empty((B, H, W, ldy), device=dev)
+    stats = torch.full((tiles, 2, ldy), float("nan"), device=dev)
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, stats=stats, ep_mode=1)
+    assert_close(from_dev_nhwc(y, Cout), yr, what="mode 1 values")
+    pt = per_tile(yr).double()
+    assert_close(stats[:, 0, :Cout].cpu(), pt.mean(-1), tol=1e-5, atol=1e-6, what="tile mean")
+    assert_close(stats[:, 1, :Cout].cpu(), ((pt - pt.mean(-1, keepdim=True)) ** 2).sum(-1), tol=1e-4, what="tile M2")
+    assert float(stats[:, :, Cout:].abs().sum()) == 0.0
+    # mode 2: dz = conv * relu'(gamma * xhat + beta), per-tile (sum dz, sum dz*xhat)
+    xz = torch.randn(B, Cout, H, W, generator=g)
+    mean, invstd = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    gamma, beta = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g) * 0.3
+    v = lambda t: t.view(1, -1, 1, 1)
+    xhat = (xz - v(mean)) * v(invstd)
+    dz_ref = yr * ((v(gamma) * xhat + v(beta)) > 0).float()
+    pad = lambda t: torch.cat([t, torch.zeros(ldy - Cout)]).to(dev)
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, stats=stats, ep_mode=2,
+           ez=(to_dev_nhwc(xz, dev), pad(mean), pad(invstd), pad(gamma), pad(beta), ops.ACT_RELU))
+    assert_close(from_dev_nhwc(y, Cout), dz_ref, what="mode 2 dz")
+    assert float(y[..., Cout:].abs().sum()) == 0.0
+    scale = float(per_tile(dz_ref.abs()).sum(-1).max())
+    assert_close(stats[:, 0, :Cout].cpu(), per_tile(dz_ref).double().sum(-1), tol=1e-5, atol=1e-5 * scale, what="sum dz")
+    assert_close(stats[:, 1, :Cout].cpu(), per_tile(dz_ref * xhat).double().sum(-1), tol=1e-5, atol=1e-5 * scale,
+                 what="sum dz*xhat")
+
+
+def test_conv3x3_small_nchw_split(dev):
+    from vision_mtl_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    B, Cin, Ca, Cb, H, W = 2, 33, 19, 1, 8, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Ca + Cb, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(Ca + Cb, generator=g)
+    oa, ob = torch.empty((B, Ca, H, W), device=dev), torch.empty((B, Cb, H, W), device=dev)
+    _small(ops, to_dev_nhwc(x, dev), _pack_fwd(ops, w, dev), oa, ceil4(Cin), ceil4(Ca + Cb), Ca + Cb, Ca + Cb,
+           bias=bias.to(dev), yb=ob, Ca=Ca)
+    yr = F.conv2d(x, w, bias, padding=1)
+    assert_close(oa.cpu(), yr[:, :Ca], what="split store head a")
+    assert_close(ob.cpu(), yr[:, Ca:], what="split store head b")
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(2, 33, 33, 19, 8, 64), (1, 16, 16, 14, 12, 32)])
+def test_decoder_tail_matches_torch(dev, training, shape):
+    """heads(relu(bn2(conv2(relu(bn1(x1)))))) and every gradient == the torch composition, in train mode (batch
+    statistics from the conv epilogues, running buffers updated) and in eval mode."""
+    from vision_mtl_amd import ops
+
+    B, C1, C2, Ca, H, W = shape
+    Cb = 1
+    g = torch.Generator().manual_seed(10)
+    x1 = torch.randn(B, C1, H, W, generator=g) * 2 + 0.5
+    bn1, bn2 = torch.nn.BatchNorm2d(C1), torch.nn.BatchNorm2d(C2)
+    for bn in (bn1, bn2):
+        bn.weight.data = torch.rand(bn.num_features, generator=g) + 0.5
+        bn.bias.data = torch.randn(bn.num_features, generator=g) * 0.2
+        bn.running_mean.data = torch.randn(bn.num_features, generator=g) * 0.1
+        bn.running_var.data = torch.rand(bn.num_features, generator=g) + 0.5
+        bn.train(training)
+    w2 = torch.randn(C2, C1, 3, 3, generator=g) / (C1 * 9) ** 0.5
+    wa, wb = torch.randn(Ca, C2, 3, 3, generator=g) * 0.1, torch.randn(Cb, C2, 3, 3, generator=g) * 0.1
+    ba, bb = torch.randn(Ca, generator=g), torch.randn(Cb, generator=g)
+    ga, gb = torch.randn(B, Ca, H, W, generator=g), torch.randn(B, Cb, H, W, generator=g)
+    import copy
+
+    bn1d, bn2d = copy.deepcopy(bn1).to(dev), copy.deepcopy(bn2).to(dev)
+    ref = [t.clone().requires_grad_(True) for t in (x1, w2, wa, ba, wb, bb)]
+    a2 = F.relu(bn2(F.conv2d(F.relu(bn1(ref[0])), ref[1], None, padding=1)))
+    ya, yb = F.conv2d(a2, ref[2], ref[3], padding=1), F.conv2d(a2, ref[4], ref[5], padding=1)
+    torch.autograd.backward([ya, yb], [ga, gb])
+
+    xd = to_dev_nhwc(x1, dev).requires_grad_(True)
+    d = [t.to(dev).requires_grad_(True) for t in (w2, wa, ba, wb, bb)]
+    assert ops.decoder_tail_supported(xd.shape, C1, C2, Ca + Cb)
+    oa, ob = ops.decoder_tail(xd, None, 0, bn1d, d[0], bn2d, d[1], d[2], d[3], d[4])
+    assert oa.is_contiguous() and ob.is_contiguous()
+    assert_close(oa.detach().cpu(), ya.detach(), what="tail head a")
+    assert_close(ob.detach().cpu(), yb.detach(), what="tail head b")
+    torch.autograd.backward([oa, ob], [ga.to(dev), gb.to(dev)])
+    assert_close(from_dev_nhwc(xd.grad, C1), ref[0].grad, tol=2e-4, what="tail dx1")
+    for i, name in enumerate(["w2", "wa", "ba", "wb", "bb"]):
+        assert_close(d[i].grad.cpu(), ref[i + 1].grad, tol=2e-4, what=f"tail d{name}")
+    for nm, a, b in (("bn1", bn1d, bn1), ("bn2", bn2d, bn2)):
+        assert_close(a.weight.grad.cpu(), b.weight.grad, tol=2e-4, what=f"tail d{nm}.weight")
+        assert_close(a.bias.grad.cpu(), b.bias.grad, tol=2e-4, what=f"tail d{nm}.bias")
+        assert_close(a.running_mean.cpu(), b.running_mean, tol=1e-5, what=f"{nm}.running_mean")
+        assert_close(a.running_var.cpu(), b.running_var, tol=1e-5, what=f"{nm}.running_var")
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked)

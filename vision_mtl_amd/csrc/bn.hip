@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           int M, int C, int Cs, float eps, float momentum,
                                                           float* running_mean, float* running_var,
                                                           long long* num_batches_tracked, float* save_mean,
-                                                          float* save_invstd) {
+                                                          float* save_invstd, const float* gamma, const float* beta,
+                                                          float* coef_a, float* coef_c) {
   __shared__ double sh[4];
   const int c = blockIdx.x;  // one workgroup per storage channel
   if (c == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (threadIdx.x == 0) {
       save_mean[c] = 0.f;
       save_invstd[c] = 0.f;
+      if (coef_a != nullptr) coef_a[c] = coef_c[c] = 0.f;
     }
     return;
   }
@@ -113,6 +115,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   if (var < 0.0) var = 0.0;
   save_mean[c] = (float)mean;
   save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (coef_a != nullptr) {  // y = act(coef_a * x + coef_c): the normalisation as the consumer conv's prologue
+    const float sc = (gamma ? gamma[c] : 1.f) * save_invstd[c];
+    coef_a[c] = sc;
+    coef_c[c] = (beta ? beta[c] : 0.f) - save_mean[c] * sc;
+  }
   if (running_mean != nullptr) {
     const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
     running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
@@ -122,17 +129,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 // eval mode: derive mean / invstd from the running buffers
 __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                     int C, int Cs, float eps, float* save_mean, float* save_invstd) {
+                                     int C, int Cs, float eps, float* save_mean, float* save_invstd,
+                                     const float* gamma, const float* beta, float* coef_a, float* coef_c) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cs) return;
-  save_mean[c] = c < C ? running_mean[c] : 0.f;
-  save_invstd[c] = c < C ? 1.f / sqrtf(running_var[c] + eps) : 0.f;
+  const float m = c < C ? running_mean[c] : 0.f;
+  const float is = c < C ? 1.f / sqrtf(running_var[c] + eps) : 0.f;
+  save_mean[c] = m;
+  save_invstd[c] = is;
+  if (coef_a != nullptr) {
+    const float sc = c < C ? (gamma ? gamma[c] : 1.f) * is : 0.f;
+    coef_a[c] = sc;
+    coef_c[c] = c < C ? (beta ? beta[c] : 0.f) - m * sc : 0.f;
+  }
 }
 
-extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
-                             int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var,
-                             long long* num_batches_tracked, float* save_mean, float* save_invstd, void* stream) {
+static int bn_stats_impl(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
+                         int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float* save_mean, float* save_invstd, const float* gamma,
+                         const float* beta, float* coef_a, float* coef_c, void* stream) {
   VMTL_ENTER();
+  if ((coef_a == nullptr) != (coef_c == nullptr)) return VMTL_ERR_ARG;
   if (!partial || !save_mean || !save_invstd || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = nblk_from_conv, rows_per_blk = rows_per_blk_from_conv;
@@ -145,8 +162,27 @@ extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partia
     return VMTL_ERR_ARG;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cs), dim3(256), 0, st, partial, nblk, rows_per_blk, M, C, Cs, eps,
-                     momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+                     momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta,
+                     coef_a, coef_c);
   return vmtl_check_launch();
+}
+
+extern "C" int vmtl_bn_stats(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
+                             int rows_per_blk_from_conv, float eps, float momentum, float* running_mean, float* running_var,
+                             long long* num_batches_tracked, float* save_mean, float* save_invstd, void* stream) {
+  return bn_stats_impl(x, M, C, Cs, partial, nblk_from_conv, rows_per_blk_from_conv, eps, momentum, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// vmtl_bn_stats that also emits the normalisation as prologue coefficients of the consumer conv
+// (vmtl_conv3x3_small: act(coef_a[c] * x + coef_c[c]); zero on the pad channels)
+extern "C" int vmtl_bn_stats_coef(const float* x, int M, int C, int Cs, float* partial, int nblk_from_conv,
+                                  int rows_per_blk_from_conv, float eps, float momentum, float* running_mean,
+                                  float* running_var, long long* num_batches_tracked, float* save_mean, float* save_invstd,
+                                  const float* gamma, const float* beta, float* coef_a, float* coef_c, void* stream) {
+  if (!coef_a || !coef_c) return VMTL_ERR_ARG;
+  return bn_stats_impl(x, M, C, Cs, partial, nblk_from_conv, rows_per_blk_from_conv, eps, momentum, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta, coef_a, coef_c, stream);
 }
 
 extern "C" int vmtl_bn_eval_stats(const float* running_mean, const float* running_var, int C, int Cs, float eps,
@@ -154,7 +190,18 @@ extern "C" int vmtl_bn_eval_stats(const float* running_mean, const float* runnin
   VMTL_ENTER();
   if (!running_mean || !running_var || !save_mean || !save_invstd || C <= 0 || C > Cs) return VMTL_ERR_ARG;
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
-                     running_var, C, Cs, eps, save_mean, save_invstd);
+                     running_var, C, Cs, eps, save_mean, save_invstd, nullptr, nullptr, nullptr, nullptr);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_bn_eval_stats_coef(const float* running_mean, const float* running_var, int C, int Cs, float eps,
+                                       float* save_mean, float* save_invstd, const float* gamma, const float* beta,
+                                       float* coef_a, float* coef_c, void* stream) {
+  VMTL_ENTER();
+  if (!running_mean || !running_var || !save_mean || !save_invstd || !coef_a || !coef_c || C <= 0 || C > Cs)
+    return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(Cs, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
+                     running_var, C, Cs, eps, save_mean, save_invstd, gamma, beta, coef_a, coef_c);
   return vmtl_check_launch();
 }
 
@@ -411,15 +458,34 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(
 }
 
 // sums the partial rows: dbeta[c] = sum dz, dgamma[c] = sum dz*xhat  (fp64, fixed order)
+// Optionally (coef_a != null, grid = Cs workgroups) also emits the backward-apply as an affine map of (dz, x):
+//   dx = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzx/M) = coef_a*dz + coef_b*x + coef_c   (train)
+//   dx = gamma*invstd*dz                                                                  (eval)
+// for a consumer that applies it while loading (vmtl_conv3x3_small prologue); zeros on the pad channels.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                              int Cs, float* sum_dz, float* sum_dzx) {
+                                                              int Cs, float* sum_dz, float* sum_dzx,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, float invM, int training,
+                                                              float* coef_a, float* coef_b, float* coef_c) {
   __shared__ double sh[4];
-  const int c = blockIdx.x;  // exactly C workgroups: the outputs may be slots of a flat gradient arena
+  const int c = blockIdx.x;  // sum outputs: exactly C entries (they may be slots of a flat gradient arena)
+  if (c >= C) {
+    if (threadIdx.x == 0 && coef_a != nullptr) coef_a[c] = coef_b[c] = coef_c[c] = 0.f;
+    return;
+  }
   const double s1 = block_rows_sum(partial, nblk, 2, 0, Cs, c, sh);
   const double s2 = block_rows_sum(partial, nblk, 2, 1, Cs, c, sh);
   if (threadIdx.x == 0) {
     sum_dz[c] = (float)s1;
     sum_dzx[c] = (float)s2;
+    if (coef_a != nullptr) {
+      const float gi = (gamma ? gamma[c] : 1.f) * invstd[c];
+      const float c1 = training ? (float)s1 * invM : 0.f, c2 = training ? (float)s2 * invM : 0.f;
+      coef_a[c] = gi;
+      coef_b[c] = -gi * invstd[c] * c2;
+      coef_c[c] = gi * (mean[c] * invstd[c] * c2 - c1);
+    }
   }
 }
 
@@ -479,7 +545,8 @@ extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, c
     VMTL_ACT_SWITCH(act, CALL)
 #undef CALL
     if (need_sums)
-      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx);
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx,
+                         nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr, nullptr);
   }
   const int nb = sweep_blocks(M, Cs);
 #define CALL(A)                                                                                              \
@@ -487,6 +554,34 @@ extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, c
                      beta, mul, sum_dz, sum_dzx, dx, M, C, Cs, training)
   VMTL_ACT_SWITCH(act, CALL)
 #undef CALL
+  return vmtl_check_launch();
+}
+
+// The two halves of vmtl_bn_bwd for producers that already emitted dz = dy * act'(z) and its per-block column sums
+// from their own epilogue (vmtl_conv3x3_small ep_mode 2, vmtl_conv2d_fwd with a BatchNorm-backward epilogue):
+// finalize sums the [nblk][2][Cs] rows (sum dz, sum dz*xhat) into the BatchNorm parameter gradients (and the
+// affine coefficients, see the kernel); apply turns (x, dz) into dx.
+extern "C" int vmtl_bn_bwd_finalize(const float* partial, int nblk, int M, int C, int Cs, float* sum_dz, float* sum_dzx,
+                                    const float* mean, const float* invstd, const float* gamma, int training,
+                                    float* coef_a, float* coef_b, float* coef_c, void* stream) {
+  VMTL_ENTER();
+  if (!partial || nblk <= 0 || M <= 0 || C <= 0 || C > Cs || !sum_dz || !sum_dzx) return VMTL_ERR_ARG;
+  const bool want = coef_a != nullptr;
+  if (want && (!coef_b || !coef_c || !mean || !invstd)) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(want ? Cs : C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, Cs,
+                     sum_dz, sum_dzx, mean, invstd, gamma, 1.f / (float)M, training, coef_a, coef_b, coef_c);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_bn_bwd_apply(const float* x, const float* dz, const float* mean, const float* invstd,
+                                 const float* gamma, const float* sum_dz, const float* sum_dzx, float* dx, int M, int C,
+                                 int Cs, int training, void* stream) {
+  VMTL_ENTER();
+  if (!x || !dz || !dx || !mean || !invstd || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  if (training && (!sum_dz || !sum_dzx)) return VMTL_ERR_ARG;
+  const int nb = sweep_blocks(M, Cs);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<VMTL_ACT_NONE>), dim3(nb), dim3(RED_THREADS), 0, (hipStream_t)stream, x, dz, mean,
+                     invstd, gamma, nullptr, nullptr, sum_dz, sum_dzx, dx, M, C, Cs, training);
   return vmtl_check_launch();
 }
 

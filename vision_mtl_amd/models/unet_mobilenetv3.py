@@ -220,6 +220,17 @@ class DecoderBlock(nn.Module):
         y = L.up2_conv_bn_act(x, skip, self.conv1[0], self.conv1[1], ACT_RELU)  # nearest x2 + cat + conv + BN + ReLU
         return L.conv_bn_act(y, self.conv2[0], self.conv2[1], ACT_RELU)
 
+    def run_conv1_raw(self, x: L.Act, skip: t.Optional[L.Act]):
+        """Only conv1 of the block, un-normalised: (raw output, its BatchNorm partial rows or None, pixels per row).
+        The caller fuses conv1's BatchNorm + ReLU into what follows (ops.decoder_tail)."""
+        c, bn = self.conv1[0], self.conv1[1]
+        y, stats = L.ops.up2_conv(x.t, x.C, None if skip is None else skip.t, c.weight, want_stats=bn.training)
+        rpb = 0
+        if stats is not None:
+            B, H2, W2, _ = x.t.shape
+            rpb = L.ops.lib().raw("vmtl_conv2d_up2_stats_block")(B, H2, W2, y.shape[3])
+        return L.Act(y, c.out_channels), stats, rpb
+
 
 class UnetDecoder(nn.Module):
     def __init__(self, encoder_channels, decoder_channels):
@@ -236,11 +247,15 @@ class UnetDecoder(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def run(self, feats: t.List[L.Act]) -> L.Act:
+    def run(self, feats: t.List[L.Act], raw_tail: bool = False):
+        """raw_tail: stop after conv1 of the LAST block and return DecoderBlock.run_conv1_raw's triple."""
         feats = feats[1:][::-1]
         x, skips = feats[0], feats[1:]
         for i, blk in enumerate(self.blocks):
-            x = blk.run(x, skips[i] if i < len(skips) else None)
+            skip = skips[i] if i < len(skips) else None
+            if raw_tail and i == len(self.blocks) - 1:
+                return blk.run_conv1_raw(x, skip)
+            x = blk.run(x, skip)
         return x
 
 
@@ -283,8 +298,8 @@ class Backbone(nn.Module):
         self.encoder = MobileNetV3Encoder(in_channels, depth=num_decoder_layers)
         self.decoder = UnetDecoder(self.encoder.out_channels[: num_decoder_layers + 1], self.decoder_channels)
 
-    def run(self, x: L.Act) -> L.Act:
-        return self.decoder.run(self.encoder.run(x))
+    def run(self, x: L.Act, raw_tail: bool = False):
+        return self.decoder.run(self.encoder.run(x), raw_tail=raw_tail)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return L.to_nchw(self.run(L.from_nchw(x)))

@@ -1026,6 +1026,179 @@ def to_nchw(x, C):
     return _ToNCHW.apply(x, C)
 
 
+# ----------------------------------------------------------------------------- narrow full-resolution tail
+def conv3x3_small_supported(Cs: int, Nw: int) -> bool:
+    return bool(lib().raw("vmtl_conv3x3_small_supported")(Cs, Nw))
+
+
+def _small(x, wp, y, B, H, W, Cs, ldy, Nw, Cout, flop, x2=None, pa=None, pb=None, pc=None, act_in=ACT_NONE, a_out=None,
+           bias=None, yb=None, Ca=0, stats=None, ep_mode=0, ez=None):
+    """One vmtl_conv3x3_small launch (csrc/conv_small.hip); ez = (x, mean, invstd, gamma, beta, act) for ep_mode 2."""
+    ez = ez or (None, None, None, None, None, ACT_NONE)
+    _k("vmtl_conv3x3_small", _flop=flop, x=x, x2=x2, pa=pa, pb=pb, pc=pc, act_in=act_in, a_out=a_out, wp=wp, bias=bias,
+       y=y, yb=yb, Ca=Ca, stats=stats, ep_mode=ep_mode, ez_x=ez[0], ez_mean=ez[1], ez_invstd=ez[2], ez_gamma=ez[3],
+       ez_beta=ez[4], ez_act=ez[5], B=B, H=H, W=W, Cs=Cs, ldy=ldy, Nw=Nw, Cout=Cout)
+
+
+def _bn_fwd_coef(x, stats, rpb, gamma, beta, rm, rv, nbt, C, training, momentum, eps):
+    """BatchNorm statistics (from conv-epilogue partial rows `stats` of `rpb` pixels each, or a sweep of x when
+    stats is None; running buffers in eval mode) -> (mean, invstd, coef_a, coef_c) with
+    BN(x) = coef_a * x + coef_c per channel (zeros on pad channels)."""
+    B, H, W, Cs = x.shape
+    M = B * H * W
+    mean, invstd, ca, cc = (_empty((Cs,), x) for _ in range(4))
+    if training:
+        if stats is not None:
+            partial, nblk = stats, stats.shape[0]
+        else:
+            partial, nblk, rpb = _empty((_reduce_rows(M), 2, Cs), x), 0, 0
+        _k("vmtl_bn_stats_coef", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk, rows_per_blk_from_conv=rpb,
+           eps=eps, momentum=momentum, running_mean=rm, running_var=rv, num_batches_tracked=nbt, save_mean=mean,
+           save_invstd=invstd, gamma=gamma, beta=beta, coef_a=ca, coef_c=cc)
+    else:
+        _k("vmtl_bn_eval_stats_coef", running_mean=rm, running_var=rv, C=C, Cs=Cs, eps=eps, save_mean=mean,
+           save_invstd=invstd, gamma=gamma, beta=beta, coef_a=ca, coef_c=cc)
+    return mean, invstd, ca, cc
+
+
+class _DecoderTail(torch.autograd.Function):
+    """relu(BN1(x1)) -> conv2 3x3 -> relu(BN2(.)) -> {head a, head b} 3x3 (+bias), returned as the reference's two
+    NCHW maps: the narrow full-resolution tail of `basic` (smp DecoderBlock conv2 of the last decoder block via
+    reference utils/model_utils.py:25-34, segm_head / depth_head of models/basic_model.py:30-51) on
+    vmtl_conv3x3_small.  x1 is the RAW output of the block's first conv (with its BatchNorm partial rows stats1):
+    both normalise+ReLU passes run as the consumer conv's prologue, both BatchNorm-backward reductions as the
+    producing data-gradient's epilogue, BN2's backward-apply as the prologue of conv2's data gradient."""
+
+    @staticmethod
+    def forward(ctx, x1, stats1, rpb1, g1, b1, rm1, rv1, nbt1, w2, g2, b2, rm2, rv2, nbt2, wa, ba, wb, bb, cfg):
+        tr1, mom1, eps1, tr2, mom2, eps2 = cfg
+        x1, w2, wa, wb = _req(x1, "x1"), _req(w2, "conv2 weight"), _req(wa, "head a weight"), _req(wb, "head b weight")
+        B, H, W, Cs1 = x1.shape
+        C2, C1 = w2.shape[0], w2.shape[1]
+        Ca, Cb = wa.shape[0], wb.shape[0]
+        N = Ca + Cb
+        ldy2, ldyh = ceil4(C2), ceil4(N)
+        if (ceil4(C1) != Cs1 or tuple(w2.shape[2:]) != (3, 3) or tuple(wa.shape[1:]) != (C2, 3, 3)
+                or tuple(wb.shape[1:]) != (C2, 3, 3) or ba is None or bb is None):
+            raise ValueError("decoder_tail: conv2 must be 3x3 over x1's channels and both heads 3x3 over conv2's, with biases")
+        if not (conv3x3_small_supported(Cs1, C2) and conv3x3_small_supported(ldy2, N) and conv3x3_small_supported(ldyh, C2)
+                and H % 4 == 0 and W % 32 == 0):
+            raise ValueError("decoder_tail: shape not covered by vmtl_conv3x3_small (use decoder_tail_supported())")
+        need_bwd = any(ctx.needs_input_grad)
+        M = B * H * W
+        tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
+        mean1, invstd1, pa1, pc1 = _bn_fwd_coef(x1, stats1, rpb1, g1, b1, rm1, rv1, nbt1, C1, tr1, mom1, eps1)
+        wp2 = packs.get(w2, "fwd", (1, C2, 9, C1, Cs1, 0, C1 * 9, 1, 9, 0))
+        a1 = _empty(x1.shape, x1) if need_bwd else None
+        x2 = _empty((B, H, W, ldy2), x1)
+        stats2 = _empty((tiles, 2, ldy2), x1) if tr2 else None
+        _small(x1, wp2, x2, B, H, W, Cs1, ldy2, C2, C2, 2.0 * M * C2 * 9 * C1, pa=pa1, pc=pc1, act_in=ACT_RELU, a_out=a1,
+               stats=stats2, ep_mode=1 if tr2 else 0)
+        mean2, invstd2, pa2, pc2 = _bn_fwd_coef(x2, stats2, 128, g2, b2, rm2, rv2, nbt2, C2, tr2, mom2, eps2)
+        wph = _empty((N, 9 * ldy2), x1)
+        pack(wa, 1, Ca, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=wph[:Ca])
+        pack(wb, 1, Cb, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=wph[Ca:])
+        bias = _empty((N,), x1)
+        _copy_vec(ba, bias, Ca)
+        _copy_vec(bb, bias[Ca:], Cb)
+        a2 = _empty(x2.shape, x1) if need_bwd else None
+        oa, ob = _empty((B, Ca, H, W), x1), _empty((B, Cb, H, W), x1)
+        _small(x2, wph, oa, B, H, W, ldy2, ldyh, N, N, 2.0 * M * N * 9 * C2, pa=pa2, pc=pc2, act_in=ACT_RELU, a_out=a2,
+               bias=bias, yb=ob, Ca=Ca)
+        ctx.save_for_backward(x1, a1, x2, a2, mean1, invstd1, mean2, invstd2, g1, b1, g2, b2, w2, wa, wb)
+        ctx.cfg = (tr1, tr2)
+        ctx.slots = tuple(_slot(t) for t in (g1, b1, w2, g2, b2, wa, ba, wb, bb))
+        return oa, ob
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        x1, a1, x2, a2, mean1, invstd1, mean2, invstd2, g1, b1, g2, b2, w2, wa, wb = ctx.saved_tensors
+        tr1, tr2 = ctx.cfg
+        sg1, sb1, sw2, sg2, sb2, swa, sba, swb, sbb = ctx.slots
+        B, H, W, Cs1 = x1.shape
+        C2, C1 = w2.shape[0], w2.shape[1]
+        Ca, Cb = wa.shape[0], wb.shape[0]
+        N = Ca + Cb
+        ldy2, ldyh = ceil4(C2), ceil4(N)
+        M = B * H * W
+        tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
+        ga = torch.zeros((B, Ca, H, W), device=x1.device) if ga is None else _req(ga, "grad a")
+        gb = torch.zeros((B, Cb, H, W), device=x1.device) if gb is None else _req(gb, "grad b")
+        dy = _empty((B, H, W, ldyh), x1)
+        dyf = dy.view(-1)
+        _k("vmtl_nchw_to_nhwc", x=ga, y=dyf, B=B, C=Ca, HW=H * W, Cs=ldyh, Cw=Ca)
+        _k("vmtl_nchw_to_nhwc", x=gb, y=dyf[Ca:], B=B, C=Cb, HW=H * W, Cs=ldyh, Cw=ldyh - Ca)  # also zeroes pad lanes
+        stamp("main tail heads")
+        fork = side.mark()
+        # heads' data gradient; epilogue = ReLU + BatchNorm-2 backward reduction (dz2 and its per-tile column sums)
+        wd = pack(wa, 1, C2, 9, Ca, ldyh, 0, 9, 1, C2 * 9, flip=1)
+        _k("vmtl_pack_weights_slice", src=wb, dst=wd.view(-1)[Ca:], R0=C2, T=9, C=Cb, group=ldyh, sr0=9, st=1, sc=C2 * 9,
+           flip=1)
+        dz2, part2 = _empty((B, H, W, ldy2), x1), _empty((tiles, 2, ldy2), x1)
+        _small(dy, wd, dz2, B, H, W, ldyh, ldy2, C2, C2, 2.0 * M * C2 * 9 * N, stats=part2, ep_mode=2,
+               ez=(x2, mean2, invstd2, g2, b2, ACT_RELU))
+        with side.branch(all(s is not None for s in (swa, sba, swb, sbb)), M, fork, a2, dy):
+            slabs, ns = _wgrad(a2, dy, B, H, W, ldy2, H, W, ldyh, N, 3, 3, 1, 1, 2.0 * M * N * 9 * C2)
+            stride = N * 9 * ldy2
+            dwa = unpack(slabs, wa.shape, 1, Ca, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=swa, nslabs=ns, slab_stride=stride)
+            dwb = unpack(slabs.view(-1)[Ca * 9 * ldy2:], wb.shape, 1, Cb, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=swb, nslabs=ns,
+                         slab_stride=stride)
+            dbias = _colsum(dy, None, M, N, ldyh)
+            dba = _empty((Ca,), x1) if sba is None else sba
+            dbb = _empty((Cb,), x1) if sbb is None else sbb
+            _copy_vec(dbias, dba, Ca)
+            _copy_vec(dbias[Ca:], dbb, Cb)
+            stamp("side tail heads")
+        # BatchNorm-2 parameter gradients + its backward-apply as affine coefficients of (dz2, x2)
+        dbeta2 = _empty((C2,), x1) if sb2 is None else sb2
+        dgamma2 = _empty((C2,), x1) if sg2 is None else sg2
+        cA, cB, cC = _empty((ldy2,), x1), _empty((ldy2,), x1), _empty((ldy2,), x1)
+        _k("vmtl_bn_bwd_finalize", partial=part2, nblk=tiles, M=M, C=C2, Cs=ldy2, sum_dz=dbeta2, sum_dzx=dgamma2, mean=mean2,
+           invstd=invstd2, gamma=g2, training=1 if tr2 else 0, coef_a=cA, coef_b=cB, coef_c=cC)
+        stamp("main tail conv2")
+        # conv2's data gradient: prologue dx2 = cA*dz2 + cB*x2 + cC (kept in dx2 for the weight gradient),
+        # epilogue = ReLU + BatchNorm-1 backward reduction
+        wd2 = packs.get(w2, "dgrad", (1, C1, 9, C2, ldy2, 0, 9, 1, C1 * 9, 1))
+        dx2 = _empty(x2.shape, x1)
+        dz1, part1 = _empty(x1.shape, x1), _empty((tiles, 2, Cs1), x1)
+        _small(dz2, wd2, dz1, B, H, W, ldy2, Cs1, C1, C1, 2.0 * M * C1 * 9 * C2, x2=x2, pa=cA, pb=cB, pc=cC, a_out=dx2,
+               stats=part1, ep_mode=2, ez=(x1, mean1, invstd1, g1, b1, ACT_RELU))
+        fork = side.mark()  # AFTER the launch above: the weight gradient reads the dx2 it wrote
+        dbeta1 = _empty((C1,), x1) if sb1 is None else sb1
+        dgamma1 = _empty((C1,), x1) if sg1 is None else sg1
+        _k("vmtl_bn_bwd_finalize", partial=part1, nblk=tiles, M=M, C=C1, Cs=Cs1, sum_dz=dbeta1, sum_dzx=dgamma1, mean=None,
+           invstd=None, gamma=None, training=1 if tr1 else 0, coef_a=None, coef_b=None, coef_c=None)
+        dx1 = None
+        if ctx.needs_input_grad[0]:
+            dx1 = _empty(x1.shape, x1)
+            _k("vmtl_bn_bwd_apply", x=x1, dz=dz1, mean=mean1, invstd=invstd1, gamma=g1, sum_dz=dbeta1, sum_dzx=dgamma1,
+               dx=dx1, M=M, C=C1, Cs=Cs1, training=1 if tr1 else 0)
+        with side.branch(sw2 is not None, M, fork, a1, dx2):
+            slabs, ns = _wgrad(a1, dx2, B, H, W, Cs1, H, W, ldy2, C2, 3, 3, 1, 1, 2.0 * M * C2 * 9 * C1)
+            dw2 = unpack(slabs, w2.shape, 1, C2, 9, C1, Cs1, 0, C1 * 9, 1, 9, out=sw2, nslabs=ns)
+            stamp("side tail conv2")
+        nif = lambda g, slot: None if slot is not None else g
+        return (dx1, None, None, nif(dgamma1, sg1), nif(dbeta1, sb1), None, None, None, nif(dw2, sw2), nif(dgamma2, sg2),
+                nif(dbeta2, sb2), None, None, None, nif(dwa, swa), nif(dba, sba), nif(dwb, swb), nif(dbb, sbb), None)
+
+
+def decoder_tail_supported(x1_shape, C1, C2, N) -> bool:
+    B, H, W, Cs1 = x1_shape
+    return (ceil4(C1) == Cs1 and conv3x3_small_supported(Cs1, C2) and conv3x3_small_supported(ceil4(C2), N)
+            and conv3x3_small_supported(ceil4(N), C2) and H % 4 == 0 and W % 32 == 0
+            and os.environ.get("VMTL_SMALL_TAIL", "1") != "0")
+
+
+def decoder_tail(x1, stats1, rpb1, bn1, conv2_weight, bn2, wa, ba, wb, bb):
+    """(head_a, head_b) NCHW = heads(relu(bn2(conv2(relu(bn1(x1)))))); bn1 / bn2 are nn.BatchNorm2d parameter
+    containers, x1 the raw conv output feeding bn1 (stats1 = its conv-epilogue partial rows of rpb1 pixels, or None)."""
+    mom = lambda bn: 0.1 if bn.momentum is None else bn.momentum
+    cfg = (bn1.training, mom(bn1), bn1.eps, bn2.training, mom(bn2), bn2.eps)
+    return _DecoderTail.apply(x1, stats1, rpb1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                              bn1.num_batches_tracked, conv2_weight, bn2.weight, bn2.bias, bn2.running_mean,
+                              bn2.running_var, bn2.num_batches_tracked, wa, ba, wb, bb, cfg)
+
+
 def _copy_vec(src, dst, n):
     """dst[:n] = src[:n] for small per-channel vectors (the pack kernel in its degenerate 1x1x1 form)."""
     _k("vmtl_pack_weights", src=src, dst=dst, R1=1, R0=1, T=1, C=n, Cs=n, sr1=0, sr0=0, st=0, sc=1, flip=0)
