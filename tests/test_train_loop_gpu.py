@@ -86,8 +86,8 @@ def test_training_loop_matches_oracle(dev, mode):
             opt = dp.ArenaAdam(arena, lr=LR)
             sched = _scheduler(opt)
             for k in range(STEPS):
+                opt.zero_grad()  # the reference's order (training_lit.py:82-87): zero_grad, step, backward, optimizer.step
                 loss = step()
-                opt.zero_grad()
                 opt.step()
                 sched.step(float(loss))
                 got.append(float(loss))

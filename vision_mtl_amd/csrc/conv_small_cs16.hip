@@ -1,0 +1,5 @@
+// vmtl_conv3x3_small instantiations for 16 input storage channels (one translation unit per channel count so
+// that the 12 kernel variants each needs compile in parallel); see conv_small.h.
+#include "conv_small.h"
+
+int vmtl_small_launch_cs16(SmallP& p, hipStream_t st) { return launch_small_cs<16>(p, st); }

@@ -53,12 +53,16 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restr
   if (threadIdx.x == 0) partial[blockIdx.x] = bs;
 }
 
-__global__ void sum_finalize_kernel(const double* __restrict__ partial, int n, double scale, float* out) {
+// err (may be null): the loss becomes NaN when the flag is set - an out-of-range class index (torch raises on it;
+// raising here would need a host sync on the step path) then fails the step VISIBLY instead of silently
+// contributing 0 to a loss still divided by P.
+__global__ void sum_finalize_kernel(const double* __restrict__ partial, int n, double scale, float* out,
+                                    const int* __restrict__ err) {
   __shared__ double shd[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
   const double t = block_sum_d(s, shd);
-  if (threadIdx.x == 0) out[0] = (float)(t * scale);
+  if (threadIdx.x == 0) out[0] = (err != nullptr && err[0] != 0) ? __int_as_float(0x7fc00000) : (float)(t * scale);
 }
 
 // dz = (softmax(z) - onehot(y)) * gout / P, written with the same strides as z.  The softmax is
@@ -77,8 +81,9 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restr
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(z[off + c * sc] - m);
     const float inv = 1.f / s;
-    const int t = (int)tgt[i];
-    for (int c = 0; c < C; ++c) dz[off + c * sc] = (expf(z[off + c * sc] - m) * inv - (c == t ? 1.f : 0.f)) * g;
+    const long long t = tgt[i];
+    const float bad = (t < 0 || t >= C) ? __int_as_float(0x7fc00000) : 0.f;  // as the forward: NaN, never a silent 0
+    for (int c = 0; c < C; ++c) dz[off + c * sc] = (expf(z[off + c * sc] - m) * inv - (c == t ? 1.f : 0.f)) * g + bad;
   }
 }
 
@@ -105,7 +110,7 @@ extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* 
   if (hipMemsetAsync(err, 0, sizeof(double), st) != hipSuccess) return VMTL_ERR_LAUNCH;
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, err, P, HW, C,
                      sb, sc, sp);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss, err);
   return vmtl_check_launch();
 }
 
@@ -247,7 +252,7 @@ extern "C" int vmtl_l1_fwd(const float* pred, const float* target, float* loss, 
   const int nblk = sl_blocks(P);
   hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblk), dim3(256), 0, st, pred, target, P, (double*)workspace);
   hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, nblk, 1.0 / (double)P,
-                     loss);
+                     loss, (const int*)nullptr);
   return vmtl_check_launch();
 }
 

@@ -23,10 +23,24 @@ class FlatArena:
     a second contiguous gradient buffer.  The backward kernels write parameter gradients directly
     into the slots (see ops._slot), so after loss.backward() `flat_grad` holds the whole gradient.
 
-    Use from a driver loop that owns the optimizer step (bench.py, Trainer below).  Do not combine
+    Replica consistency: when torch.distributed is initialised the flat parameter buffer and every
+    floating-point buffer (BatchNorm running statistics) are broadcast from rank 0 here, so ranks
+    whose models were initialised under different seeds start identical (what DDP does in its
+    constructor).  BatchNorm statistics are per replica afterwards (PyTorch-DDP default; the reference is
+    single-device, there is no SyncBN to mirror): running buffers drift apart by the shard statistics and
+    `broadcast_buffers()` re-aligns them to rank 0's (call it before evaluating / checkpointing).
+
+    Gradient semantics: a backward pass OVERWRITES the slot of every parameter its kernels compute a
+    gradient for (it does not accumulate: one fwd+bwd per optimizer step, as the reference's loop,
+    training_lit.py:82-87).  Gradients that reach an arena parameter through ordinary autograd (a
+    torch-native loss term on a parameter) are added in place by AccumulateGrad instead; a parameter
+    that gets BOTH kinds in one backward pass would depend on their order, so that raises.  zero_grad()
+    is one memset of the flat buffer (needed only for the autograd-accumulated kind).
+
+    Use from a driver loop that owns the optimizer step (bench.py, ArenaAdam below).  Do not combine
     with optimizer.zero_grad(set_to_none=True): .grad must stay bound to the arena."""
 
-    def __init__(self, model: torch.nn.Module):
+    def __init__(self, model: torch.nn.Module, broadcast: bool = True):
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
@@ -34,7 +48,8 @@ class FlatArena:
         total = sum(p.numel() for p in params)
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.params, off = params, 0
+        self.params, self.offsets, off = params, [], 0
+        self._kernel_written = set()  # ids of parameters whose slot a HIP backward kernel writes (ops._slot)
         for p in params:
             n = p.numel()
             slot = self.flat_param[off:off + n].view(p.shape)
@@ -42,14 +57,69 @@ class FlatArena:
             p.data = slot
             p.grad = self.flat_grad[off:off + n].view(p.shape)
             p._vmtl_gslot = p.grad
+            p._vmtl_arena = self
+            p.register_hook(self._make_mixed_use_guard(p))
+            self.offsets.append(off)
             off += n
         self.numel = total
+        self.model = model
         self._adam = None
+        self.pending_scale = 1.0  # 1/world still to be applied to flat_grad (see all_reduce_mean / ArenaAdam)
+        if broadcast:
+            self.broadcast_parameters()
+
+    # ---- replica consistency
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Rank `src`'s parameters and floating-point buffers to every rank (no-op without a process group)."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        dist.broadcast(self.flat_param, src=src)
+        self.broadcast_buffers(src)
+        ops.packs.invalidate()
+
+    def broadcast_buffers(self, src: int = 0) -> None:
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src)
+
+    def checksum(self) -> float:
+        """Cheap cross-rank consistency probe: max over ranks of |sum(params) - rank 0's sum| (0.0 when identical)."""
+        s = self.flat_param.double().sum().reshape(1)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            ref = s.clone()
+            dist.broadcast(ref, src=0)
+            d = (s - ref).abs()
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)
+            return float(d.item())
+        return 0.0
+
+    # ---- gradient bookkeeping
+    def _make_mixed_use_guard(self, p):
+        def guard(grad):
+            if grad is not None and id(p) in self._kernel_written:  # kernels that wrote the slot hand autograd None
+                raise RuntimeError(
+                    "a parameter of the FlatArena receives a gradient through ordinary autograd AND from a HIP "
+                    "backward kernel that overwrites its slot in the same backward pass: the result would depend on "
+                    "their order.  Keep torch-native loss terms off parameters the vmtl kernels differentiate.")
+            return grad
+        return guard
+
+    def zero_grad(self) -> None:
+        """One memset of the whole gradient buffer (slots written by kernels do not need it: they are overwritten)."""
+        self.flat_grad.zero_()
+        self.pending_scale = 1.0
 
     def all_reduce_mean(self):
-        """Average the flat gradient over all ranks: one RCCL all-reduce."""
+        """Average the flat gradient over all ranks: ONE collective.  On RCCL (backend nccl) the averaging is the
+        collective's own reduction op (no extra pass over the 54 MB buffer) and 1.0 is returned; on backends without
+        AVG (gloo: the CPU tests) the sum is reduced and the factor 1/world is returned for the caller to fold into
+        its next pass over the gradient (ArenaAdam: grad_scale of the fused Adam launch)."""
         ops.side.join()  # no-op unless a backward pass ended abnormally with side-stream work un-joined
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG)
+                return 1.0
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0
@@ -57,15 +127,19 @@ class FlatArena:
     def sync_loss(self, loss: torch.Tensor) -> torch.Tensor:
         """Return `loss` with the gradient averaging hooked onto its backward pass: when the autograd
         engine finishes `loss.backward()` (engine callback, queued from the root of the graph) the side
-        stream is joined, the flat gradient is all-reduced once over RCCL and scaled by 1/world - so the
-        reference's `loss.backward(); optimizer.step()` (training_lit.py:85-87) needs no change
-        (last row).  MTLModule does this for the train stage when `dp_arena` is set."""
+        stream is joined and the flat gradient is all-reduced once over RCCL - so the reference's
+        `loss.backward(); optimizer.step()` (training_lit.py:85-87) needs no change (SURVEY.md section 8b,
+        last row).  MTLModule does this for the train stage when `dp_arena` is set.  A remaining 1/world factor
+        (gloo only) is applied in place unless an ArenaAdam is attached, which folds it into its update."""
         return _SyncGrads.apply(loss, self)
 
     def _end_of_backward(self):
         scale = self.all_reduce_mean()
         if scale != 1.0:
-            self.flat_grad.mul_(scale)
+            if getattr(self, "_scale_consumer", None) is not None:
+                self.pending_scale = scale  # ArenaAdam.step() passes it as grad_scale: no extra pass
+            else:
+                self.flat_grad.mul_(scale)
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         """torch.optim.Adam semantics (reference training_lit.py:51,87) as ONE fused launch over the arena."""
@@ -81,36 +155,82 @@ class FlatArena:
 
 
 class ArenaAdam(torch.optim.Optimizer):
-    """torch.optim.Adam's interface over FlatArena.adam_step (one fused launch over the flat buffers):
-    `param_groups`, `state_dict` / `load_state_dict` and `zero_grad` behave like an optimizer's, so the
-    reference's scheduler (`ReduceLROnPlateau`, training_lit.py:51-55) and checkpoint writer
-    (`save_ckpt`, pipeline_utils.py:139-167) drive the arena path unchanged."""
+    """torch.optim.Adam's interface over FlatArena.adam_step (one fused launch over the flat buffers).
+    `param_groups`, `zero_grad` and the `state_dict` WIRE FORMAT are torch.optim.Adam's: state_dict() emits
+    {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{..., "params": [0..n-1]}]} with the
+    moments sliced per parameter out of the flat buffers (parameter order = model.parameters(), the order
+    torch.optim.Adam(module.parameters()) uses), and load_state_dict() accepts exactly that - so the reference's
+    scheduler (`ReduceLROnPlateau`, training_lit.py:51-55) drives it unchanged and session_{epoch}.pt files
+    written by `save_ckpt` (pipeline_utils.py:139-167) move between this optimizer and torch.optim.Adam in both
+    directions.  Anything else raises (never a silent partial load)."""
 
     def __init__(self, arena: "FlatArena", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.arena = arena
         super().__init__([arena.flat_param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        arena._scale_consumer = self
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
-        self.arena.adam_step(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+        scale, self.arena.pending_scale = self.arena.pending_scale, 1.0
+        self.arena.adam_step(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
+                             grad_scale=scale)
         return loss
 
     def zero_grad(self, set_to_none: bool = False):
-        """Nothing to clear: every backward pass overwrites the gradient slots (it never accumulates)."""
+        """One memset of the flat gradient buffer (`set_to_none` is ignored: .grad must stay bound to the arena)."""
+        self.arena.zero_grad()
 
     def state_dict(self):
-        st = self.arena._adam
-        return {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                "arena": None if st is None else {k: v.clone() for k, v in st.items()}}
+        a, st = self.arena, self.arena._adam
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(a.params)))
+        state = {}
+        if st is not None:
+            for i, (p, off) in enumerate(zip(a.params, a.offsets)):
+                n = p.numel()
+                state[i] = {"step": st["step"].detach().clone().reshape(()).cpu(),
+                            "exp_avg": st["m"][off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": st["v"][off:off + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update(saved)
-        if sd.get("arena") is not None:
-            dev = self.arena.flat_param.device
-            self.arena._adam = {k: v.to(dev).clone() for k, v in sd["arena"].items()}
+        a = self.arena
+        if not isinstance(sd, dict) or "param_groups" not in sd or "state" not in sd:
+            raise ValueError("ArenaAdam.load_state_dict: expected a torch.optim.Adam state_dict ('state' + 'param_groups')")
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if ids != list(range(len(a.params))):
+            raise ValueError(f"ArenaAdam.load_state_dict: the checkpoint covers {len(ids)} parameters, the arena holds "
+                             f"{len(a.params)} (parameter order must be model.parameters())")
+        hyper = [{k: v for k, v in g.items() if k != "params"} for g in groups]
+        if any(h != hyper[0] for h in hyper[1:]):
+            raise ValueError("ArenaAdam.load_state_dict: parameter groups with different hyper-parameters are not supported")
+        for k in ("amsgrad", "maximize"):
+            if hyper[0].get(k):
+                raise ValueError(f"ArenaAdam.load_state_dict: {k}=True is not implemented by the fused update")
+        self.param_groups[0].update({k: v for k, v in hyper[0].items() if k in self.param_groups[0]})
+        state = sd["state"]
+        if not state:
+            a._adam = None
+            return
+        if sorted(state.keys()) != list(range(len(a.params))):
+            raise ValueError("ArenaAdam.load_state_dict: 'state' must hold every parameter (a partially stepped optimizer "
+                             "cannot be represented by one fused step counter)")
+        dev = a.flat_param.device
+        m, v = torch.zeros_like(a.flat_param), torch.zeros_like(a.flat_param)
+        steps = set()
+        for i, (p, off) in enumerate(zip(a.params, a.offsets)):
+            e, n = state[i], p.numel()
+            if tuple(e["exp_avg"].shape) != tuple(p.shape) or tuple(e["exp_avg_sq"].shape) != tuple(p.shape):
+                raise ValueError(f"ArenaAdam.load_state_dict: moment shapes of parameter {i} do not match {tuple(p.shape)}")
+            m[off:off + n].copy_(e["exp_avg"].reshape(-1))
+            v[off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+            steps.add(float(e["step"]))
+        if len(steps) != 1:
+            raise ValueError("ArenaAdam.load_state_dict: parameters with different step counts cannot share the fused update")
+        a._adam = {"m": m, "v": v, "step": torch.full((1,), steps.pop(), dtype=torch.float32, device=dev)}
 
 
 class _SyncGrads(torch.autograd.Function):

@@ -37,6 +37,14 @@ def to_nchw(a: Act) -> torch.Tensor:
     return ops.to_nchw(a.t, a.C)
 
 
+def _momentum(bn: nn.BatchNorm2d) -> float:
+    if bn.momentum is None:
+        # torch switches to a cumulative moving average (factor 1/num_batches_tracked), which needs the counter on
+        # the host; the reference never uses it (every BatchNorm2d is built with the default 0.1)
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
+    return float(bn.momentum)
+
+
 def _pair(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
@@ -65,7 +73,7 @@ def conv_bn_act(x: Act, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | N
 
 def bn_act(x: Act, bn: nn.BatchNorm2d, act: int, mul: Act | None = None, res: Act | None = None,
            stats=None) -> Act:
-    momentum = 0.1 if bn.momentum is None else bn.momentum
+    momentum = _momentum(bn)
     y = ops.bn_act(x.t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, x.C,
                    bn.training, momentum, bn.eps, act, mul=None if mul is None else mul.t,
                    res=None if res is None else res.t, stats=stats)

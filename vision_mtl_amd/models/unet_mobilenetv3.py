@@ -16,6 +16,7 @@ Param-less children (act / drop / Identity modules) are kept on purpose: the ref
 from __future__ import annotations
 
 import math
+import os
 import typing as t
 
 import torch
@@ -290,13 +291,28 @@ class Backbone(nn.Module):
         super().__init__()
         if encoder_name != "timm-mobilenetv3_large_100":
             raise NotImplementedError(f"encoder {encoder_name!r}: only timm-mobilenetv3_large_100 is restated")
+        weights_file = None
         if encoder_weights is not None:
-            raise RuntimeError(
-                f"encoder_weights={encoder_weights!r} needs a network download; pass None (random init) or load a "
-                "state_dict afterwards")
+            # the reference hands "imagenet" to smp, which downloads the timm checkpoint (a network fetch).  Offline the
+            # same state_dict can be supplied as a local file: a path given directly, or $VMTL_ENCODER_WEIGHTS
+            weights_file = encoder_weights if os.path.isfile(str(encoder_weights)) else os.environ.get("VMTL_ENCODER_WEIGHTS")
+            if not weights_file or not os.path.isfile(weights_file):
+                raise RuntimeError(
+                    f"encoder_weights={encoder_weights!r} is a network download in the reference (smp -> timm).  Offline: "
+                    "pass encoder_weights=None (random init; the reference CLI's default --backbone_weights), a path to a "
+                    "local mobilenetv3_large_100 state_dict, or set VMTL_ENCODER_WEIGHTS to such a file")
         self.decoder_channels = [decoder_first_channel // (2 ** i) for i in range(num_decoder_layers)]
         self.encoder = MobileNetV3Encoder(in_channels, depth=num_decoder_layers)
         self.decoder = UnetDecoder(self.encoder.out_channels[: num_decoder_layers + 1], self.decoder_channels)
+        if weights_file is not None:
+            sd = torch.load(weights_file, map_location="cpu")
+            sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+            own = self.encoder.model.state_dict()
+            # timm's classifier checkpoint also carries conv_head / classifier: features_only drops them
+            missing = [k for k in own if k not in sd]
+            if missing:
+                raise RuntimeError(f"{weights_file}: not a mobilenetv3_large_100 state_dict (missing {missing[:3]} ...)")
+            self.encoder.model.load_state_dict({k: sd[k] for k in own})
 
     def run(self, x: L.Act, raw_tail: bool = False):
         return self.decoder.run(self.encoder.run(x), raw_tail=raw_tail)

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import weakref
 
 import torch
 
@@ -69,7 +70,12 @@ def _slot(p):
     slot exists the backward kernels write the parameter gradient straight into it and autograd is
     told there is nothing to accumulate: gradients of the whole model then form ONE contiguous buffer
     (one RCCL all-reduce, one fused Adam launch) without per-parameter add / copy kernels."""
-    return None if p is None else getattr(p, "_vmtl_gslot", None)
+    if p is None:
+        return None
+    slot = getattr(p, "_vmtl_gslot", None)
+    if slot is not None:
+        p._vmtl_arena._kernel_written.add(id(p))  # dp.FlatArena's guard against mixed gradient paths
+    return slot
 
 
 def _empty(shape, like):
@@ -179,29 +185,50 @@ class _PackCache:
     storage, autograd version and the global epoch are unchanged (torch optimizers bump the version;
     FlatArena.adam_step() and refresh() bump the epoch).  refresh() re-packs every known entry with a
     single vmtl_pack_weights_batch launch; a miss falls back to an individual pack and marks the
-    descriptor table for a rebuild (done outside graph capture, during warm-up)."""
+    descriptor table for a rebuild (done outside graph capture, during warm-up).
+
+    Weights are held by WEAK reference: the entries (and their packed device buffers) of a model that has
+    been dropped are purged by the next refresh() instead of being re-packed forever - a process that
+    builds several models (the reference's hyperparam_tuning.py loop, a train-then-eval pair, the test
+    session) neither leaks device memory nor slows down with the number of dead models."""
 
     def __init__(self):
-        self.entries = {}  # key -> dict(dst, params, weight_ref, ptr, version, epoch)
-        self.custom = {}   # key -> dict(dst, fn, weight, ptr, version, epoch): operands with their own pack kernel
+        self.entries = {}  # key -> dict(dst, params, wref, ptr, version, epoch)
+        self.custom = {}   # key -> dict(dst, fn, wref, ptr, version, epoch): operands with their own pack kernel
         self.epoch = 0
         self.table = None  # (device uint8 tensor, n, total)
+        self.live = []
         self.dirty = True
         self.custom_ready = None  # event: this step's custom operands are packed (side stream)
 
     def invalidate(self):
         self.epoch += 1
 
+    @staticmethod
+    def _alive(e):
+        w = e["wref"]()
+        return w is not None and w.data_ptr() == e["ptr"]
+
+    def purge(self):
+        """Drop the entries of weights that no longer exist (or moved, e.g. into a FlatArena)."""
+        n = len(self.entries) + len(self.custom)
+        self.entries = {k: e for k, e in self.entries.items() if self._alive(e)}
+        self.custom = {k: e for k, e in self.custom.items() if self._alive(e)}
+        if len(self.entries) + len(self.custom) != n:
+            self.dirty = True
+
     def get(self, weight, kind, params, offset=0):
         """params = (R1, R0, T, C, Cs, sr1, sr0, st, sc, flip); offset = first element of the weight to read."""
         key = (id(weight), kind, params, offset)
         e = self.entries.get(key)
+        if e is not None and e["wref"]() is not weight:  # id() of a dead tensor reused by a new one
+            e = None
         if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
             return e["dst"]
         R1, R0, T, C, Cs = params[:5]
         if e is None or e["ptr"] != weight.data_ptr():
-            e = {"dst": _empty((R1 * R0, T * Cs), weight), "params": params, "weight": weight, "ptr": weight.data_ptr(),
-                 "offset": offset}
+            e = {"dst": _empty((R1 * R0, T * Cs), weight), "params": params, "wref": weakref.ref(weight),
+                 "ptr": weight.data_ptr(), "offset": offset}
             self.entries[key] = e
             self.dirty = True
         pack(weight.view(-1)[offset:] if offset else weight, *params, out=e["dst"])
@@ -214,11 +241,13 @@ class _PackCache:
         event wait on first use)."""
         key = (id(weight), kind)
         e = self.custom.get(key)
+        if e is not None and e["wref"]() is not weight:
+            e = None
         if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
             self.join()
             return e["dst"]
         if e is None or e["ptr"] != weight.data_ptr():
-            e = {"dst": _empty(shape, weight), "fn": fn, "weight": weight, "ptr": weight.data_ptr()}
+            e = {"dst": _empty(shape, weight), "fn": fn, "wref": weakref.ref(weight), "ptr": weight.data_ptr()}
             self.custom[key] = e
         fn(weight, e["dst"])
         e["version"], e["epoch"] = weight._version, self.epoch
@@ -233,8 +262,6 @@ class _PackCache:
     def _build_table(self):
         import struct
 
-        # entries whose weight moved (e.g. into a FlatArena) are dead: get() made fresh ones for the new storage
-        self.entries = {k: e for k, e in self.entries.items() if e["weight"].data_ptr() == e["ptr"]}
         live = list(self.entries.values())
         if not live:
             self.table, self.live, self.dirty = None, [], False
@@ -254,21 +281,25 @@ class _PackCache:
     def refresh(self):
         """Re-pack every known weight (call once at the start of a step, before the forward)."""
         self.join()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.purge()  # never while capturing: the captured table must keep describing the same launches
         if not self.entries and not self.custom:
             return
         self.epoch += 1
         if self.dirty:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 return  # keep per-call packing inside this capture; the table is rebuilt on the next eager step
             self._build_table()
         if self.table is not None:
             table, n, total = self.table
             _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
             for e in self.live:
-                e["version"], e["epoch"] = e["weight"]._version, self.epoch
+                w = e["wref"]()
+                if w is not None:
+                    e["version"], e["epoch"] = w._version, self.epoch
         # operands with their own pack kernels (up2 phase / gradient matrices): none is needed before the
         # decoder, so they are built on the side stream while the encoder runs
-        self.custom = {k: e for k, e in self.custom.items() if e["weight"].data_ptr() == e["ptr"]}
         if self.custom:
             use_side = side.enabled
             if use_side:
@@ -280,8 +311,11 @@ class _PackCache:
                 ctx = contextlib.nullcontext()
             with ctx:
                 for e in self.custom.values():
-                    e["fn"](e["weight"], e["dst"])
-                    e["version"], e["epoch"] = e["weight"]._version, self.epoch
+                    w = e["wref"]()
+                    if w is None:
+                        continue
+                    e["fn"](w, e["dst"])
+                    e["version"], e["epoch"] = w._version, self.epoch
                 if use_side:
                     ev = torch.cuda.Event()
                     ev.record()
@@ -1192,7 +1226,11 @@ def decoder_tail_supported(x1_shape, C1, C2, N) -> bool:
 def decoder_tail(x1, stats1, rpb1, bn1, conv2_weight, bn2, wa, ba, wb, bb):
     """(head_a, head_b) NCHW = heads(relu(bn2(conv2(relu(bn1(x1)))))); bn1 / bn2 are nn.BatchNorm2d parameter
     containers, x1 the raw conv output feeding bn1 (stats1 = its conv-epilogue partial rows of rpb1 pixels, or None)."""
-    mom = lambda bn: 0.1 if bn.momentum is None else bn.momentum
+    def mom(bn):
+        if bn.momentum is None:
+            raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
+        return float(bn.momentum)
+
     cfg = (bn1.training, mom(bn1), bn1.eps, bn2.training, mom(bn2), bn2.eps)
     return _DecoderTail.apply(x1, stats1, rpb1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
                               bn1.num_batches_tracked, conv2_weight, bn2.weight, bn2.bias, bn2.running_mean,
