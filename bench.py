@@ -52,7 +52,7 @@ def build(args, device):
 
 
 def make_batch(args, device, rank):
-    from oracle.losses import synthetic_batch
+    from vision_mtl_amd.data import synthetic_batch
 
     b = synthetic_batch(args.batch, args.height, args.width, args.classes, seed=11 + rank)
     return {k: v.to(device) for k, v in b.items()}

@@ -206,6 +206,9 @@ int vmtl_argmax_channels(const float* z, long long* out, int B, int HW, int C, l
                          long long sp, void* stream);
 int vmtl_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, int Cs, int Cw, void* stream);
 int vmtl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, int Cs, void* stream);
+/* input side (lit_module.py:211-219 + the dataset sample contract of data_modules/cityscapes.py:39-83,
+ * nyuv2.py:100-141): HWC pixel rows [P][C] -> internal NHWC storage [P][Cs] (zero pad channels), y = x * scale */
+int vmtl_hwc_to_nhwc_pad(const float* x, float* y, long long P, int C, int Cs, float scale, void* stream);
 
 /* ---- losses ------------------------------------------------------------------------------
  * lit_module.py:31,123 (CrossEntropyLoss); losses.py:14-36 (SILogLoss); lit_module.py:68,112 (MAE). */

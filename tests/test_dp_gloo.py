@@ -29,9 +29,22 @@ def _worker(rank, world, port, tmp):
 
     r, w, _ = dp.init_distributed()
     assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
-    torch.manual_seed(5)
+    # a rank that was seeded differently (the reference never seeds: cfg.py:194 is unused) is repaired by the
+    # broadcast FlatArena does at construction; without it the replicas would silently diverge
+    torch.manual_seed(5 + 100 * rank)
     model = MTANMiniUnet(3, {"depth": 1, "segm": 4}, 8, 4, 2).eval()
+    with torch.no_grad():
+        for b in model.buffers():
+            if b.is_floating_point():
+                b.add_(0.25 * rank)
+    lone = dp.FlatArena(MTANMiniUnet(3, {"depth": 1, "segm": 4}, 8, 4, 2), broadcast=False)
+    assert lone.checksum() > 0.0  # un-broadcast replicas differ and the probe sees it
     arena = dp.FlatArena(model)
+    assert arena.checksum() == 0.0
+    torch.manual_seed(5)
+    want = MTANMiniUnet(3, {"depth": 1, "segm": 4}, 8, 4, 2).state_dict()
+    got = model.state_dict()
+    assert all(torch.equal(got[k], want[k]) for k in want), "rank 0's parameters / buffers everywhere"
     assert arena.flat_grad.numel() == sum(p.numel() for p in model.parameters())
     assert all(p.data_ptr() >= arena.flat_param.data_ptr() for p in model.parameters())
     full = synthetic_batch(4, 16, 16, 4, seed=3)

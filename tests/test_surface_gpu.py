@@ -1,0 +1,333 @@
+"""-m gpu: the rest of the step surface and the "next" rows of SURVEY.md section 8(f) on the HIP path -
+per-step metrics (F1, reference lit_module.py:48-69,106-118), input hand-over (F4, lit_module.py:211-219 + the
+sample contract of data_modules/cityscapes.py:39-67), calc_loss (A18, utils/loss_utils.py:8-24),
+validation_step / test_step under no_grad with the model left in train mode (A14, training_lit.py:115-139),
+checkpoint round trip on the device (F3), and the robustness items of the round-1 review."""
+import argparse
+import gc
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------------------------------ F1 metrics
+def _metrics_cpu(pred, target, C, beta=1.0):
+    """torchmetrics 0.7.3 definitions (package not installable offline: restated from its documentation).
+    Accuracy(average="micro"), JaccardIndex(num_classes=C) = mean over classes of tp/(tp+fp+fn) with absent_score 0,
+    FBetaScore(average="weighted", mdmc_average="global") = support-weighted mean of the per-class F-beta."""
+    pred, target = pred.reshape(-1), target.reshape(-1)
+    cm = torch.zeros(C, C, dtype=torch.int64)
+    cm.index_put_((target, pred), torch.ones_like(target), accumulate=True)
+    tp = cm.diag().double()
+    fn, fp = cm.sum(1).double() - tp, cm.sum(0).double() - tp
+    acc = tp.sum() / cm.sum()
+    union = tp + fp + fn
+    jac = torch.where(union > 0, tp / union.clamp_min(1), torch.zeros_like(tp)).mean()
+    den = (1 + beta ** 2) * tp + beta ** 2 * fn + fp
+    f = torch.where(den > 0, (1 + beta ** 2) * tp / den.clamp_min(1), torch.zeros_like(tp))
+    support = cm.sum(1).double()
+    return cm, float(acc), float(jac), float((f * support).sum() / support.sum())
+
+
+@pytest.mark.parametrize("C", [19, 14])
+def test_segm_metrics_match_definitions(dev, C):
+    from vision_mtl_amd import metrics as M
+
+    g = torch.Generator().manual_seed(C)
+    target = torch.randint(0, C - 2, (3, 40, 56), generator=g)  # classes C-2, C-1 never occur as targets
+    pred = torch.where(torch.rand(target.shape, generator=g) < 0.7, target, torch.randint(0, C - 1, target.shape, generator=g))
+    # class C-1 is absent from predictions AND targets (Jaccard term 0); class C-2 only appears as a false positive
+    cm_ref, acc, jac, fb = _metrics_cpu(pred, target, C)
+    assert int(cm_ref[C - 1].sum()) == 0 and int(cm_ref[:, C - 1].sum()) == 0
+    cm = M.confusion_matrix(pred.to(dev), target.to(dev), C)
+    assert torch.equal(cm.cpu().long(), cm_ref)  # integer counts: exact
+    for cls, ref in ((M.Accuracy, acc), (M.JaccardIndex, jac), (M.FBetaScore, fb)):
+        got = float(cls(C)(pred.to(dev), target.to(dev)))
+        assert abs(got - ref) <= 1e-6, (cls.__name__, got, ref)
+    d = torch.rand(3, 40, 56, 1, generator=g)
+    t = torch.rand(3, 40, 56, 1, generator=g)
+    assert abs(float(M.MeanAbsoluteError()(d.to(dev), t.to(dev))) - float((d - t).abs().mean())) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------ F4 input side
+def test_sample_layout_upload_matches_the_nchw_path(dev):
+    """HWC sample batch -> pinned upload -> one relayout kernel -> the model sees exactly what it sees for the
+    reference's transposed NCHW batch; the returned img is the reference's (B,3,H,W) tensor."""
+    from vision_mtl_amd import data
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.models.mtan_model import MTANMiniUnet
+
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 2, 32, 48, 5
+    raws = [{"img": torch.rand(H, W, 3, generator=g).numpy(), "mask": torch.randint(-1, C - 1, (H, W), generator=g).numpy(),
+             "depth": (torch.rand(H, W, generator=g) * 0.49).numpy()} for _ in range(B)]
+    host = data.collate([data.prepare_sample(r, C) for r in raws])
+    assert host["img"].is_pinned() and tuple(host["img"].shape) == (B, H, W, 3)
+    torch.manual_seed(1)
+    module = MTLModule(MTANMiniUnet(3, {"depth": 1, "segm": C}, 8, 4, 2).to(dev).train(), num_classes=C, device=str(dev))
+    batch = module.transfer_batch_to_device(dict(host), dev, 0)
+    assert tuple(batch["img"].shape) == (B, 3, H, W) and batch["img"].is_cuda and batch["mask"].dtype == torch.int64
+    assert torch.equal(batch["img"].cpu(), host["img"].permute(0, 3, 1, 2))
+    st = batch["img"]._vmtl_nhwc
+    assert tuple(st.shape) == (B, H, W, 4) and float(st[..., 3].abs().sum()) == 0.0  # pad lane zero
+    ref_batch = {"img": host["img"].permute(0, 3, 1, 2).contiguous().to(dev), "mask": batch["mask"], "depth": batch["depth"]}
+    sd0 = {k: v.clone() for k, v in module.model.state_dict().items()}
+    la = module.training_step(batch, 0)
+    module.model.load_state_dict(sd0)
+    lb = module.training_step(ref_batch, 0)
+    assert torch.equal(la, lb)
+
+
+# ------------------------------------------------------------------------------------------ A14 / A18 step surface
+def _tiny_module(dev, fx):
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.models.mtan_model import MTANMiniUnet
+
+    c = fx["cfg"]
+    m = MTANMiniUnet(3, dict(fx["tasks"]), c["hidden"], c["first"], c["levels"])
+    m.load_state_dict(fx["state_dict"])
+    return MTLModule(m.to(dev), num_classes=c["C"], lr=5e-4, device=str(dev))
+
+
+def test_validation_and_test_step_no_grad_train_mode(dev):
+    """run_pipe validates under torch.no_grad() WITHOUT module.eval() (training_lit.py:115-139): batch statistics
+    are used and the running buffers move exactly as in a training step - pinned by the reference's golden."""
+    fx = torch.load(os.path.join(G, "mtan_tiny.pt"), weights_only=False)
+    batch = {k: v.to(dev) for k, v in fx["batch"].items()}
+    for stage, fn in (("val", "validation_step"), ("test", "test_step")):
+        module = _tiny_module(dev, fx)
+        module.train()
+        with torch.no_grad():
+            loss = getattr(module, fn)(batch, 0)
+        assert not loss.requires_grad
+        assert_close(loss.cpu(), fx["loss"], tol=1e-4, what=f"{stage} loss")
+        sd = module.model.state_dict()
+        for k, v in fx["state_dict_after"].items():
+            if "running" in k:
+                assert_close(sd[k].cpu(), v, tol=1e-4, what=k)
+            elif "num_batches" in k:
+                assert int(sd[k]) == int(v)
+        so = module.step_outputs[stage]
+        assert len(so["loss"]) == 1 and all(len(so[k]) == 1 for k in ("accuracy", "jaccard_index", "fbeta_score", "mae"))
+        summary = getattr(module, "on_validation_epoch_end" if stage == "val" else "on_test_epoch_end")()
+        assert abs(summary[f"{stage}/loss"] - float(fx["loss"])) <= 1e-4 * float(fx["loss"]) and not so["loss"]
+
+
+def test_calc_loss_and_l1_and_optimizers(dev):
+    from vision_mtl_amd.losses import CrossEntropyLoss, L1Loss, SILogLoss
+    from vision_mtl_amd.utils.loss_utils import calc_loss
+
+    fx = torch.load(os.path.join(G, "mtan_tiny.pt"), weights_only=False)
+    module = _tiny_module(dev, fx)
+    module.train()
+    batch = {k: v.to(dev) for k, v in fx["batch"].items()}
+    out = module(batch["img"])
+    loss = calc_loss(out, batch["mask"], batch["depth"], CrossEntropyLoss(), SILogLoss())  # utils/loss_utils.py:8-24
+    assert_close(loss.detach().cpu(), fx["loss"], tol=1e-4, what="calc_loss")  # unweighted sum == the step loss (w = 1)
+    pred = torch.sigmoid(out["depth"].detach()).permute(0, 2, 3, 1)
+    l1 = L1Loss()(pred.contiguous().requires_grad_(True), batch["depth"])
+    assert_close(l1.detach().cpu(), (pred - batch["depth"]).abs().mean().cpu(), tol=1e-6, what="L1Loss")
+    cfg = module.configure_optimizers()  # reference lit_module.py:193-209
+    assert isinstance(cfg["optimizer"], torch.optim.Adam) and cfg["optimizer"].param_groups[0]["lr"] == 5e-4
+    assert cfg["lr_scheduler"]["monitor"] == "train_loss"
+    assert sum(p.numel() for p in cfg["optimizer"].param_groups[0]["params"]) == sum(p.numel() for p in module.model.parameters())
+
+
+# ------------------------------------------------------------------------------------------ F3 on the device
+def test_checkpoint_round_trip_reproduces_eval_outputs(dev, tmp_path):
+    from vision_mtl_amd.utils import ckpt
+
+    fx = torch.load(os.path.join(G, "mtan_tiny.pt"), weights_only=False)
+    module = _tiny_module(dev, fx)
+    module.model.load_state_dict(fx["state_dict_after"])
+    opt = torch.optim.Adam(module.parameters(), lr=5e-4)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=2, factor=0.9)
+    ckpt.save_ckpt(module, opt, sched, 4, str(tmp_path / "model_4.pt"), str(tmp_path / "session_4.pt"))
+    fresh = _tiny_module(dev, fx)
+    with torch.no_grad():
+        for p in fresh.parameters():
+            p.zero_()
+    fresh.load_state_dict(ckpt.load_ckpt_model(str(tmp_path))["model"])
+    fresh.eval()
+    with torch.no_grad():
+        out = fresh(fx["batch"]["img"].to(dev))
+    for t, ref in fx["out_eval"].items():  # the REFERENCE's eval outputs for these weights
+        assert_close(out[t].cpu(), ref, tol=1e-4, what=f"eval out {t} after reload")
+
+
+# ------------------------------------------------------------------------------------------ robustness
+def test_cross_entropy_out_of_range_target_is_nan_not_silent(dev):
+    from vision_mtl_amd import ops
+
+    z = torch.randn(2, 5, 8, 8, device=dev, requires_grad=True)
+    t = torch.randint(0, 5, (2, 8, 8), device=dev)
+    assert torch.isfinite(ops.cross_entropy(z, t))
+    t[0, 0, 0] = 255  # an unmapped "ignore" label: torch raises, the HIP path must not silently average it in
+    loss = ops.cross_entropy(z, t)
+    assert torch.isnan(loss)
+    loss.backward()
+    assert torch.isnan(z.grad[0, :, 0, 0]).all()
+    t[0, 0, 0] = -1
+    assert torch.isnan(ops.cross_entropy(z, t))
+
+
+def test_pack_cache_does_not_keep_dead_models(dev):
+    from vision_mtl_amd import ops
+    from vision_mtl_amd.models.mtan_model import MTANMiniUnet
+
+    x = torch.rand(1, 3, 16, 16, device=dev)
+
+    def run_one():
+        m = MTANMiniUnet(3, {"depth": 1, "segm": 3}, 8, 4, 2).to(dev).eval()
+        with torch.no_grad():
+            m(x)
+
+    run_one()
+    gc.collect()
+    ops.packs.refresh()
+    torch.cuda.synchronize()
+    base_entries, base_mem = len(ops.packs.entries) + len(ops.packs.custom), torch.cuda.memory_allocated()
+    for _ in range(6):
+        run_one()
+        gc.collect()
+    ops.packs.refresh()  # purges the operands of the dead models
+    torch.cuda.synchronize()
+    assert len(ops.packs.entries) + len(ops.packs.custom) <= base_entries
+    assert torch.cuda.memory_allocated() <= base_mem + (1 << 20)
+
+
+# ------------------------------------------------------------------------------------------ production widths / sizes
+@pytest.mark.parametrize("size", [32, 64])
+def test_mtan_production_widths_match_oracle(dev, size):
+    """build_model("mtan") exactly as the reference builds it (first 32, hidden 128, C = 14): outputs 1e-4, loss 1e-4,
+    gradients 1e-3 against oracle/mtan.py, which the reference's own golden vectors pin (tests/test_oracle_golden.py)."""
+    from oracle.losses import step_losses, synthetic_batch
+    from oracle.mtan import mtan_forward
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    model = build_model(argparse.Namespace(model_name="mtan", backbone_weights=None), argparse.Namespace(num_classes=14))
+    assert sum(p.numel() for p in model.parameters()) == 13_277_743
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    batch = synthetic_batch(1, size, size, 14, seed=11, masked=0.1)
+    out_ref = mtan_forward(sd, batch["img"], ["depth", "segm"], 4, training=True)
+    loss_ref = step_losses(out_ref, batch["mask"], batch["depth"])["loss"]
+    loss_ref.backward()
+    model = model.to(dev).train()
+    module = MTLModule(model, num_classes=14, device=str(dev))
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    out = model(dbatch["img"])
+    for t in ("depth", "segm"):
+        assert_close(out[t].detach().cpu(), out_ref[t].detach(), tol=1e-4, what=f"train out {t}")
+    model.load_state_dict(sd0)
+    loss = module.training_step(dbatch, 0)
+    loss.backward()
+    assert_close(loss.detach().cpu(), loss_ref.detach(), tol=1e-4, what="loss")
+    gscale = max(float(v.grad.abs().max()) for v in leaves.values())
+    for k, p in model.named_parameters():
+        assert_close(p.grad.cpu(), leaves[k].grad, tol=1e-3, atol=1e-6 * gscale, what=f"grad {k}")
+
+
+@pytest.mark.parametrize("name", ["basic", "csnet"])
+def test_forward_and_loss_at_the_baseline_spatial_size(dev, name):
+    """BASELINE.json configs 2/3 at their stated 128x256 resolution (batch 2 so the CPU oracle finishes in seconds)."""
+    from oracle.losses import step_losses, synthetic_batch
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    model = build_model(argparse.Namespace(model_name=name, backbone_weights=None, channel_wise_stitching=True),
+                        argparse.Namespace(num_classes=19))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synthetic_batch(2, 128, 256, 19, seed=11, masked=0.1)
+    with torch.no_grad():
+        if name == "basic":
+            from oracle.unet_mobilenetv3 import basic_forward
+
+            out_ref = basic_forward(sd, batch["img"], True)
+        else:
+            from oracle.cross_stitch import csnet_forward
+
+            out_ref = csnet_forward(sd, batch["img"], ["depth", "segm"], True)
+        loss_ref = step_losses(out_ref, batch["mask"], batch["depth"])["loss"]
+    model = model.to(dev).train()
+    module = MTLModule(model, num_classes=19, device=str(dev))
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    with torch.no_grad():
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        out = model(dbatch["img"])
+        model.load_state_dict(sd0)
+        loss = module.validation_step(dbatch, 0)
+    for t in ("depth", "segm"):
+        assert tuple(out[t].shape) == tuple(out_ref[t].shape)
+        assert_close(out[t].cpu(), out_ref[t], tol=1e-4, what=f"{name} out {t} @128x256")
+    assert_close(loss.cpu(), loss_ref, tol=1e-4, what=f"{name} loss @128x256")
+
+
+FULL = [("basic", 32, 128, 256, 19), ("csnet", 32, 128, 256, 19), ("mtan", 16, 256, 256, 14)]
+
+
+@pytest.mark.parametrize("name,B,H,W,C", FULL)
+def test_full_size_properties(dev, name, B, H, W, C):
+    """BASELINE.json configs 2-4 at FULL size, through size-independent properties: the training step is finite and
+    every gradient exists; in eval mode (BatchNorm = running statistics: images do not interact) images 0-1 of the
+    full batch equal a batch-2 run (to fp32 summation order: the GEMM tile shape follows the row count), and the
+    batch-2 run equals the CPU oracle within 1e-4."""
+    from oracle.losses import synthetic_batch
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    model = build_model(argparse.Namespace(model_name=name, backbone_weights=None, channel_wise_stitching=True),
+                        argparse.Namespace(num_classes=C))
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():  # non-trivial running statistics for the eval-mode comparison
+        for k, v in model.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+            elif k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.5 + 0.75)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synthetic_batch(B, H, W, C, seed=11, masked=0.05)
+    model = model.to(dev)
+    module = MTLModule(model, num_classes=C, device=str(dev))
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    model.train()
+    loss = module.training_step(dbatch, 0)
+    loss.backward()
+    assert torch.isfinite(loss)
+    used = [p for p in model.parameters() if p.grad is not None]
+    assert name == "csnet" or len(used) == len(list(model.parameters()))
+    assert all(torch.isfinite(p.grad).all() for p in used)
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        full = model(dbatch["img"])
+        two = model(dbatch["img"][:2].contiguous())
+        if name == "basic":
+            from oracle.unet_mobilenetv3 import basic_forward
+
+            ref = basic_forward(sd, batch["img"][:2], False)
+        elif name == "csnet":
+            from oracle.cross_stitch import csnet_forward
+
+            ref = csnet_forward(sd, batch["img"][:2], ["depth", "segm"], False)
+        else:
+            from oracle.mtan import mtan_forward
+
+            ref = mtan_forward(sd, batch["img"][:2], ["depth", "segm"], 4, False)
+    for t in ("depth", "segm"):
+        assert tuple(full[t].shape) == (B, 1 if t == "depth" else C, H, W)
+        assert torch.isfinite(full[t]).all()
+        assert_close(full[t][:2].cpu(), two[t].cpu(), tol=2e-5, what=f"{name} {t}: images 0-1 of the full batch vs a batch of 2")
+        assert_close(two[t].cpu(), ref[t], tol=1e-4, what=f"{name} eval {t} at {H}x{W}")

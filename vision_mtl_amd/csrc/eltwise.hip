@@ -516,3 +516,23 @@ extern "C" int vmtl_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW,
                      total);
   return vmtl_check_launch();
 }
+
+// Dataset sample layout -> model input layout in one pass: x is [P][C] (HWC pixels as the reference's .npy / PNG
+// samples store them: data_modules/cityscapes.py:69-83, nyuv2.py:100-141), y is the internal NHWC storage
+// [P][Cs] with zero pad channels; y = x * scale (scale = 1/255 for 8-bit sources that were not rescaled on the host).
+__global__ __launch_bounds__(256) void hwc_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Cs,
+                                                      float scale, long long total) {
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cs);
+    const long long pix = i / Cs;
+    y[i] = c < C ? x[pix * C + c] * scale : 0.f;
+  }
+}
+
+extern "C" int vmtl_hwc_to_nhwc_pad(const float* x, float* y, long long P, int C, int Cs, float scale, void* stream) {
+  VMTL_ENTER();
+  if (!x || !y || P <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  const long long total = P * Cs;
+  hipLaunchKernelGGL(hwc_pad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, Cs, scale, total);
+  return vmtl_check_launch();
+}

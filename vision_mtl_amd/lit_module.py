@@ -129,16 +129,17 @@ class MTLModule(nn.Module):
                 "lr_scheduler": {"scheduler": scheduler, "interval": "epoch", "monitor": "train_loss"}}
 
     def transfer_batch_to_device(self, batch: dict, device, dataloader_idx: int = 0):
-        # pinned host tensors (DataLoader(pin_memory=True)) go up asynchronously on the current stream; the model
-        # re-lays the NCHW image to its NHWC storage format on the device (vmtl_nchw_to_nhwc)
-        def up(t):
-            return t.to(device, non_blocking=t.device.type == "cpu" and t.is_pinned())
+        """reference lit_module.py:211-219.  Pinned host tensors (DataLoader(pin_memory=True), data.collate) go up
+        asynchronously on the current stream; an image batch kept in dataset sample layout (B,H,W,3) is re-laid on
+        the device by one kernel straight into the model's input storage (data.upload_batch)."""
+        from .data import upload_batch
 
         if isinstance(batch, dict):
+            up = upload_batch(batch, device)
             for key in batch.keys():
-                batch[key] = up(batch[key])
+                batch[key] = up[key]
             return batch
-        return up(batch)
+        return batch.to(device, non_blocking=batch.device.type == "cpu" and batch.is_pinned())
 
     def parameters(self, recurse: bool = True):  # reference lit_module.py:232-234
         for p in self.model.parameters():

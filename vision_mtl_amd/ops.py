@@ -1032,7 +1032,23 @@ class _ToNHWC(torch.autograd.Function):
 
 
 def to_nhwc(x):
+    st = getattr(x, "_vmtl_nhwc", None)
+    if st is not None and st.shape[0] == x.shape[0] and tuple(st.shape[1:3]) == tuple(x.shape[2:]) and not x.requires_grad:
+        return st  # produced by hwc_to_model_input: already the internal storage, no relayout
     return _ToNHWC.apply(x)
+
+
+def hwc_to_model_input(x_hwc, scale: float = 1.0):
+    """(B,H,W,C) device tensor in dataset sample layout -> the reference's (B,C,H,W) input tensor, backed by the
+    model's internal NHWC storage (zero pad channels) which to_nhwc() picks up without a second relayout."""
+    x_hwc = _req(x_hwc, "img")
+    B, H, W, C = x_hwc.shape
+    Cs = ceil4(C)
+    st = _empty((B, H, W, Cs), x_hwc)
+    _k("vmtl_hwc_to_nhwc_pad", x=x_hwc, y=st, P=B * H * W, C=C, Cs=Cs, scale=scale)
+    view = st[..., :C].permute(0, 3, 1, 2)
+    view._vmtl_nhwc = st
+    return view
 
 
 class _ToNCHW(torch.autograd.Function):
