@@ -54,6 +54,15 @@ int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
 int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
 
+/* vmtl_conv2d_fwd used as a DATA GRADIENT with the BatchNorm + activation backward of the layer that produced the
+ * differentiated tensor fused into the epilogue (reference utils/model_utils.py:72-76 run backwards): y = conv *
+ * act'(ez_gamma*xhat + ez_beta), xhat = (ez_x - ez_mean)*ez_invstd; stats[vmtl_conv2d_stats_rows(B,Ho,Wo,ldy)][2][ldy] =
+ * per-row-block (sum y, sum y*xhat) -> vmtl_bn_bwd_finalize -> vmtl_bn_bwd_apply. */
+int vmtl_conv2d_bnbwd(const float* x, const float* wp, float* y, float* stats, const float* ez_x, const float* ez_mean,
+                      const float* ez_invstd, const float* ez_gamma, const float* ez_beta, int ez_act, int B, int H,
+                      int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride, int pad,
+                      void* stream);
+
 /* nearest-x2 upsample of xl + concat with skip + 3x3/pad-1 conv (smp DecoderBlock entry, reference
  * utils/model_utils.py:25-34) as four 2x2 phase convolutions on the low-res map: wp_eff from
  * vmtl_pack_up2_fwd ([4][Cout][4*C0s + 9*C1s]); y is [B][2*H2][2*W2][ldy].  Backward uses
@@ -80,13 +89,16 @@ int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits,
  *   prologue: v = act_in(pa[c]*x + pb[c]*x2 + pc[c]) once per input element (pa null: identity; x2/pb null:
  *             one operand); a_out (optional, needs pa) receives the transformed input.
  *   ep_mode 0: y = conv + bias.  yb != null: NCHW split store, channels [0,Ca) -> y [B][Ca][H][W], the rest -> yb.
- *   ep_mode 1: y = conv, stats[tile][2][ldy] = per-tile (mean, M2) of y (tiles of 128 pixels, vmtl_conv3x3_small_tiles).
+ *   ep_mode 1: y = conv, stats[row][2][ldy] = (mean, M2) of y over the row's pixels; rows / pixels per row:
+ *              vmtl_conv3x3_small_stat_rows / _stat_block (a row is one 128-pixel tile, or all tiles of a workgroup).
  *   ep_mode 2: y = conv * act'(z), z = ez_gamma*xhat + ez_beta, xhat = (ez_x - ez_mean)*ez_invstd (BatchNorm + activation
  *              backward of the layer that produced the tensor whose gradient this conv computes);
- *              stats[tile][2][ldy] = per-tile (sum y, sum y*xhat).
+ *              stats[row][2][ldy] = (sum y, sum y*xhat) over the row's pixels.
  * ep_mode 1/2 need H % 4 == 0 and W % 32 == 0. */
 int vmtl_conv3x3_small_supported(int Cs, int Nw);
 int vmtl_conv3x3_small_tiles(int B, int H, int W);
+int vmtl_conv3x3_small_stat_rows(int B, int H, int W);  /* rows of stats ... */
+int vmtl_conv3x3_small_stat_block(int B, int H, int W); /* ... and the pixels each row covers */
 int vmtl_conv3x3_small(const float* x, const float* x2, const float* pa, const float* pb, const float* pc,
                        int act_in, float* a_out, const float* wp, const float* bias, float* y, float* yb, int Ca,
                        float* stats, int ep_mode, const float* ez_x, const float* ez_mean, const float* ez_invstd,
@@ -218,6 +230,10 @@ int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void*
                 int C, long long sb, long long sc, long long sp, void* stream);
 int vmtl_ce_bwd(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
                 int HW, int C, long long sb, long long sc, long long sp, void* stream);
+/* as vmtl_ce_bwd with separate strides (dsb, dsc, dsp) for dlogits, e.g. NHWC (HW*ld, 1, ld) */
+int vmtl_ce_bwd_strided(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
+                        int HW, int C, long long sb, long long sc, long long sp, long long dsb, long long dsc,
+                        long long dsp, void* stream);
 long long vmtl_silog_workspace_bytes(long long P);
 int vmtl_silog_fwd(const float* pred, const float* target, float min_depth, float* loss, float* stats,
                    void* workspace, long long P, void* stream);

@@ -75,6 +75,9 @@ def test_conv3x3_small_epilogues(dev, case):
     yr = F.conv2d(x, w, None, padding=1)
     tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
     assert tiles == B * (H // 4) * (W // 32)
+    # few tiles: one statistics row per tile (= per workgroup), 128 pixels each
+    assert lib().raw("vmtl_conv3x3_small_stat_rows")(B, H, W) == tiles
+    assert lib().raw("vmtl_conv3x3_small_stat_block")(B, H, W) == 128
 
     def per_tile(t):  # (B,C,H,W) -> (tiles, C, 128) in the kernel's tile order (image, tile row, tile column)
         return t.view(B, -1, H // 4, 4, W // 32, 32).permute(0, 2, 4, 1, 3, 5).reshape(tiles, t.shape[1], 128)
@@ -104,6 +107,44 @@ def test_conv3x3_small_epilogues(dev, case):
     assert_close(stats[:, 0, :Cout].cpu(), per_tile(dz_ref).double().sum(-1), tol=1e-5, atol=1e-5 * scale, what="sum dz")
     assert_close(stats[:, 1, :Cout].cpu(), per_tile(dz_ref * xhat).double().sum(-1), tol=1e-5, atol=1e-5 * scale,
                  what="sum dz*xhat")
+
+
+def test_conv3x3_small_statistics_accumulated_per_workgroup(dev):
+    """More tiles than workgroup slots: every persistent workgroup folds its tiles into ONE statistics row
+    ((mean, M2) merged with Chan's formula, plain sums added); merged over rows they must give the tensor's statistics."""
+    from vision_mtl_amd import ops
+    from vision_mtl_amd._lib import lib
+
+    B, Cin, Cout, H, W = 8, 33, 33, 64, 256
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.5
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    Cs, ldy = ceil4(Cin), ceil4(Cout)
+    rows, blk = lib().raw("vmtl_conv3x3_small_stat_rows")(B, H, W), lib().raw("vmtl_conv3x3_small_stat_block")(B, H, W)
+    tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
+    assert rows < tiles and rows * blk == B * H * W, (rows, blk, tiles)
+    xd, wp = to_dev_nhwc(x, dev), _pack_fwd(ops, w, dev)
+    yr = F.conv2d(x, w, None, padding=1).double()
+    y = torch.empty((B, H, W, ldy), device=dev)
+    stats = torch.full((rows, 2, ldy), float("nan"), device=dev)
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, stats=stats, ep_mode=1)
+    st = stats.cpu().double()
+    mean = st[:, 0, :Cout].mean(0)  # equal-sized rows
+    m2 = st[:, 1, :Cout].sum(0) + blk * ((st[:, 0, :Cout] - mean) ** 2).sum(0)
+    assert_close(mean, yr.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="merged mean")
+    assert_close(m2 / (B * H * W), yr.var((0, 2, 3), unbiased=False), tol=1e-4, what="merged variance")
+    xz = torch.randn(B, Cout, H, W, generator=g)
+    vec = [torch.rand(Cout, generator=g) + 0.5 for _ in range(4)]
+    v = lambda t: t.view(1, -1, 1, 1)
+    xhat = (xz - v(vec[0])) * v(vec[1])
+    dz = yr.float() * ((v(vec[2]) * xhat + v(vec[3])) > 0).float()
+    pad = lambda t: torch.cat([t, torch.zeros(ldy - Cout)]).to(dev)
+    _small(ops, xd, wp, y, Cs, ldy, Cout, Cout, stats=stats, ep_mode=2,
+           ez=(to_dev_nhwc(xz, dev), pad(vec[0]), pad(vec[1]), pad(vec[2]), pad(vec[3]), ops.ACT_RELU))
+    st = stats.cpu().double()
+    scale = float(dz.abs().double().sum((0, 2, 3)).max())
+    assert_close(st[:, 0, :Cout].sum(0), dz.double().sum((0, 2, 3)), tol=1e-5, atol=1e-6 * scale, what="total sum dz")
+    assert_close(st[:, 1, :Cout].sum(0), (dz * xhat).double().sum((0, 2, 3)), tol=1e-5, atol=1e-6 * scale, what="total sum dz*xhat")
 
 
 def test_conv3x3_small_nchw_split(dev):
@@ -169,3 +210,62 @@ def test_decoder_tail_matches_torch(dev, training, shape):
         assert_close(a.running_mean.cpu(), b.running_mean, tol=1e-5, what=f"{nm}.running_mean")
         assert_close(a.running_var.cpu(), b.running_var, tol=1e-5, what=f"{nm}.running_var")
         assert int(a.num_batches_tracked) == int(b.num_batches_tracked)
+
+
+# B, C (channels of x), Cout, C1 (skip channels, up2 only), H, W, up2
+BNCONV_CASES = [(2, 33, 33, 0, 16, 24, False), (2, 67, 33, 0, 12, 20, True), (1, 135, 67, 16, 8, 12, True),
+                (2, 20, 67, 24, 9, 7, True), (1, 64, 128, 0, 8, 8, False)]  # last: split-K data gradient -> unfused fallback
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("case", BNCONV_CASES)
+def test_bn_act_conv_matches_torch(dev, case, training):
+    """ops.bn_act_conv (pre-activation node: BatchNorm + ReLU + the consuming conv, with the BatchNorm-backward
+    reduction in the data gradient's epilogue) == the torch composition, values and every gradient."""
+    import copy
+
+    from vision_mtl_amd import ops
+
+    B, C, Cout, C1, H, W, up2 = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g) * 0.2
+    bn.running_mean.data = torch.randn(C, generator=g) * 0.1
+    bn.running_var.data = torch.rand(C, generator=g) + 0.5
+    bn.train(training)
+    bnd = copy.deepcopy(bn).to(dev)
+    w = torch.randn(Cout, C + C1, 3, 3, generator=g) / ((C + C1) * 9) ** 0.5
+    skip = torch.randn(B, C1, 2 * H, 2 * W, generator=g) if C1 else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    skr = skip.clone().requires_grad_(True) if C1 else None
+    a = F.relu(bn(xr))
+    if up2:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+        a = torch.cat([a, skr], 1) if C1 else a
+    yr = F.conv2d(a, wr, None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    skd = to_dev_nhwc(skip, dev).requires_grad_(True) if C1 else None
+    y, stats, rpb = ops.bn_act_conv(xd, None, 0, bnd, C, ops.ACT_RELU, wd, skip=skd, up2=up2, want_stats=True)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="bn_act_conv fwd")
+    if stats is not None:  # the raw output's own BatchNorm partial rows (for the NEXT node)
+        st = stats.cpu().double()
+        M = yr.shape[0] * yr.shape[2] * yr.shape[3]
+        nrows = [min(rpb, M - i * rpb) for i in range(st.shape[0])] if not up2 else [rpb] * st.shape[0]
+        cnt = torch.tensor(nrows, dtype=torch.float64).view(-1, 1)
+        mean = (st[:, 0, :Cout] * cnt).sum(0) / M
+        assert_close(mean, yr.detach().double().mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="output stats mean")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=2e-4, what="bn_act_conv dx")
+    assert_close(wd.grad.cpu(), wr.grad, tol=2e-4, what="bn_act_conv dw")
+    assert_close(bnd.weight.grad.cpu(), bn.weight.grad, tol=2e-4, what="bn_act_conv dgamma")
+    assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="bn_act_conv dbeta")
+    if C1:
+        assert_close(from_dev_nhwc(skd.grad, C1), skr.grad, tol=2e-4, what="bn_act_conv dskip")
+    assert_close(bnd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
+    assert_close(bnd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")

@@ -204,28 +204,38 @@ def test_pack_cache_does_not_keep_dead_models(dev):
 
 
 # ------------------------------------------------------------------------------------------ production widths / sizes
-@pytest.mark.parametrize("size", [32, 64])
-def test_mtan_production_widths_match_oracle(dev, size):
-    """build_model("mtan") exactly as the reference builds it (first 32, hidden 128, C = 14): outputs 1e-4, loss 1e-4,
-    gradients 1e-3 against oracle/mtan.py, which the reference's own golden vectors pin (tests/test_oracle_golden.py)."""
+@pytest.mark.parametrize("size,B", [(32, 2), (64, 1)])
+def test_mtan_production_widths_match_oracle(dev, size, B):
+    """build_model("mtan") exactly as the reference builds it (first 32, hidden 128, C = 14) against oracle/mtan.py,
+    which the reference's own golden vectors pin (tests/test_oracle_golden.py): outputs and loss within 1e-4.
+    Gradients: these maps are tiny (a 2x2 bottleneck at 32x32), so ~70 stacked train-mode BatchNorms normalise over a
+    handful of values and two fp32 implementations differ by more than 1e-3 on single tensors (measured: the fp32 CPU
+    oracle against its own fp64 run does too) - the bar is the fp64-anchored one of tests/util.py."""
     from oracle.losses import step_losses, synthetic_batch
     from oracle.mtan import mtan_forward
+    from tests.util import assert_grads_as_good_as_fp32_cpu
     from vision_mtl_amd.lit_module import MTLModule
     from vision_mtl_amd.utils.pipeline_utils import build_model
 
     torch.manual_seed(11)
     model = build_model(argparse.Namespace(model_name="mtan", backbone_weights=None), argparse.Namespace(num_classes=14))
     assert sum(p.numel() for p in model.parameters()) == 13_277_743
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
-    batch = synthetic_batch(1, size, size, 14, seed=11, masked=0.1)
-    out_ref = mtan_forward(sd, batch["img"], ["depth", "segm"], 4, training=True)
-    loss_ref = step_losses(out_ref, batch["mask"], batch["depth"])["loss"]
-    loss_ref.backward()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synthetic_batch(B, size, size, 14, seed=11, masked=0.1)
+
+    def cpu(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+        out = mtan_forward(sd, batch["img"].to(dtype), ["depth", "segm"], 4, training=True)
+        loss = step_losses(out, batch["mask"], batch["depth"].to(dtype))["loss"]
+        loss.backward()
+        return out, loss, {k: v.grad for k, v in leaves.items()}
+
+    out_ref, loss_ref, g32 = cpu(torch.float32)
+    _, _, g64 = cpu(torch.float64)
     model = model.to(dev).train()
     module = MTLModule(model, num_classes=14, device=str(dev))
     dbatch = {k: v.to(dev) for k, v in batch.items()}
-    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     out = model(dbatch["img"])
     for t in ("depth", "segm"):
         assert_close(out[t].detach().cpu(), out_ref[t].detach(), tol=1e-4, what=f"train out {t}")
@@ -233,9 +243,7 @@ def test_mtan_production_widths_match_oracle(dev, size):
     loss = module.training_step(dbatch, 0)
     loss.backward()
     assert_close(loss.detach().cpu(), loss_ref.detach(), tol=1e-4, what="loss")
-    gscale = max(float(v.grad.abs().max()) for v in leaves.values())
-    for k, p in model.named_parameters():
-        assert_close(p.grad.cpu(), leaves[k].grad, tol=1e-3, atol=1e-6 * gscale, what=f"grad {k}")
+    assert_grads_as_good_as_fp32_cpu({k: p.grad.cpu() for k, p in model.named_parameters()}, g64, g32)
 
 
 @pytest.mark.parametrize("name", ["basic", "csnet"])

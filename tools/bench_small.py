@@ -37,7 +37,7 @@ def timeit(fn):
     return e0.elapsed_time(e1) / args.reps * 1e3
 
 
-tiles = L.raw("vmtl_conv3x3_small_tiles")(B, H, W)
+tiles = L.raw("vmtl_conv3x3_small_stat_rows")(B, H, W)
 for name, Cin, Cout in [("conv2 33->33", 33, 33), ("heads 33->20", 33, 20), ("heads dgrad 20->33", 20, 33)]:
     if args.only and args.only not in name:
         continue

@@ -56,6 +56,15 @@ struct ConvP {
   // split-K (launches without bias / activation / stats / shuffle only): blockIdx.y = K slice, every
   // slice writes its partial tile to ksl_out + slice * M * ldy; vmtl_sum_slabs adds them into y.
   int ksplit, ksteps_per_split;
+  // BatchNorm + activation BACKWARD of the layer that produced the tensor whose gradient this launch computes
+  // (data-gradient launches only; ez_x = null: off): y = acc * act'(gamma*xhat + beta), xhat = (ez_x - mean)*invstd,
+  // and stats[tile_m][2][ldy] = per-row-block column sums (sum y, sum y*xhat) instead of (mean, M2).
+  const float* ez_x;  // [M][ldy], the producer's pre-BatchNorm activation
+  const float* ez_mean;
+  const float* ez_invstd;
+  const float* ez_gamma;
+  const float* ez_beta;
+  int ez_act;
 };
 
 // NT > 0: the last NT output columns of the tile ("tail") are not given an MFMA tile of their own; every
@@ -419,6 +428,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
   }
 
+  // ---- BatchNorm-backward epilogue (see ConvP::ez_x): dz = acc * act'(z) in place, with the column sums ----
+  float zs1[TN], zs2[TN];
+  if (p.ez_x != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 16 + l15;
+      const bool nok = n < p.Cout;
+      const float em = nok ? p.ez_mean[n] : 0.f, ei = nok ? p.ez_invstd[n] : 0.f;
+      const float eg = nok ? p.ez_gamma[n] : 0.f, eb = nok ? p.ez_beta[n] : 0.f;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + (wm * TM + i) * 16 + 4 * lq + r;
+          float v = 0.f;
+          if (nok && m < p.M) {
+            const float xh = (p.ez_x[(size_t)m * p.ldy + n] - em) * ei;
+            v = acc[i][j][r] * act_grad(eg * xh + eb, p.ez_act);
+            a1 += v;
+            a2 += v * xh;
+          }
+          acc[i][j][r] = v;
+        }
+      zs1[j] = a1;
+      zs2[j] = a2;
+    }
+  }
+
   // ---- epilogue: bias + activation, zero the pad channels, store ----
   // C layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int hw = p.Ho * p.Wo;
@@ -460,7 +498,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 
   // ---- tail columns: fold the four k quarters, lanes of quarter 0 own one output row each ----
-  float tv[TM][NT > 0 ? NT : 1];
+  float tv[TM][NT > 0 ? NT : 1], txh[TM][NT > 0 ? NT : 1];
   if (NT > 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -473,6 +511,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         const int m = m0 + (wm * TM + i) * 16 + l15;
         const float bt = (p.bias != nullptr && n < p.Nw) ? p.bias[n] : 0.f;
         v = (n < p.Cout) ? act_fwd(v + bt, p.act) : 0.f;
+        if (p.ez_x != nullptr) {  // BatchNorm-backward epilogue on the tail column (one pixel per lane of quarter 0)
+          float xh = 0.f;
+          if (n < p.Cout && m < p.M) {
+            xh = (p.ez_x[(size_t)m * p.ldy + n] - p.ez_mean[n]) * p.ez_invstd[n];
+            v *= act_grad(p.ez_gamma[n] * xh + p.ez_beta[n], p.ez_act);
+          } else {
+            v = 0.f;
+          }
+          txh[i][t] = xh;
+        }
         tv[i][t] = v;
         if (lq == 0 && m < p.M && n < p.ldy) {
           if (UP2) {
@@ -490,7 +538,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // block-local MEAN and M2 = sum (v - mean)^2 (two in-register passes).  The finalize kernel
   // merges blocks with Chan's parallel-variance formula in fp64, so the variance never goes
   // through E[x^2] - E[x]^2 (which loses everything when |mean| >> std).
-  if (p.stats != nullptr) {
+  if (p.stats != nullptr && p.ez_x != nullptr) {
+    // column sums (sum dz, sum dz*xhat) of this row block: lane quarters -> waves -> one row pair per block
+    float* red = smem;  // [2][WAVES_M][BN]; the staging tiles are dead after the last barrier
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float a1 = zs1[j], a2 = zs2[j];
+      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+      if (lq == 0) {
+        red[wm * BN + (wn * TN + j) * 16 + l15] = a1;
+        red[(WAVES_M + wm) * BN + (wn * TN + j) * 16 + l15] = a2;
+      }
+    }
+    if (NT > 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          a1 += tv[i][t];
+          a2 += tv[i][t] * txh[i][t];
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a1 += __shfl_xor(a1, o, 64);
+          a2 += __shfl_xor(a2, o, 64);
+        }
+        if (lane == 0) {
+          red[wm * BN + BNM + t] = a1;
+          red[(WAVES_M + wm) * BN + BNM + t] = a2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) {
+        a1 += red[w * BN + c];
+        a2 += red[(WAVES_M + w) * BN + c];
+      }
+      const int n = n0 + c;
+      if (n < p.ldy) {
+        p.stats[((size_t)tile_m * 2 + 0) * p.ldy + n] = a1;
+        p.stats[((size_t)tile_m * 2 + 1) * p.ldy + n] = a2;
+      }
+    }
+  } else if (p.stats != nullptr) {
     float* red = smem;  // [2][WAVES_M][BN]; the staging tiles are dead after the last barrier
     const int nvalid = min(BM, p.M - m0);
     auto colval = [&](int i, int j, int r, float& v) -> bool {
@@ -936,9 +1031,11 @@ extern "C" int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot) {
   return s < 2 ? 1 : (int)s;
 }
 
-extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
-                               int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
-                               int KH, int KW, int stride, int pad, int act, int shuffle, void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* wp, const float* bias, float* y, float* stats,
+                           int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
+                           int KH, int KW, int stride, int pad, int act, int shuffle, const float* ez_x,
+                           const float* ez_mean, const float* ez_invstd, const float* ez_gamma, const float* ez_beta,
+                           int ez_act, void* stream) {
   VMTL_ENTER();
   if (!x || !wp || !y) return VMTL_ERR_ARG;
   if (Cs <= 0 || (Cs & 3) || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return VMTL_ERR_ARG;
@@ -953,6 +1050,7 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
   p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
   p.act = act; p.shuffle = shuffle; p.x2 = nullptr; p.C2s = 0; p.ksplit = 1; p.ksteps_per_split = 0;
+  p.ez_x = ez_x; p.ez_mean = ez_mean; p.ez_invstd = ez_invstd; p.ez_gamma = ez_gamma; p.ez_beta = ez_beta; p.ez_act = ez_act;
   hipStream_t st = (hipStream_t)stream;
   if (shuffle && ldy > Cout &&  // the scatter only writes co < Cout: keep the pad-channel invariant
       hipMemsetAsync(y, 0, (size_t)B * 4 * Ho * Wo * ldy * sizeof(float), st) != hipSuccess)
@@ -977,6 +1075,25 @@ extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bia
   }
 }
 
+extern "C" int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
+                               int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
+                               int KH, int KW, int stride, int pad, int act, int shuffle, void* stream) {
+  return conv2d_fwd_impl(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, act, shuffle,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Data gradient with the BatchNorm + activation backward of the producer of the differentiated tensor fused into
+// the epilogue (ConvP::ez_x): y = dz, stats[vmtl_conv2d_stats_rows(...)][2][ldy] = per-row-block (sum dz, sum dz*xhat).
+// The caller finishes with vmtl_bn_bwd_finalize + vmtl_bn_bwd_apply (no reduce pass over x and dy).
+extern "C" int vmtl_conv2d_bnbwd(const float* x, const float* wp, float* y, float* stats, const float* ez_x,
+                                 const float* ez_mean, const float* ez_invstd, const float* ez_gamma,
+                                 const float* ez_beta, int ez_act, int B, int H, int W, int Cs, int Ho, int Wo, int ldy,
+                                 int Nw, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  if (!stats || !ez_x || !ez_mean || !ez_invstd || !ez_gamma || !ez_beta) return VMTL_ERR_ARG;
+  return conv2d_fwd_impl(x, wp, nullptr, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, 0, 0, ez_x,
+                         ez_mean, ez_invstd, ez_gamma, ez_beta, ez_act, stream);
+}
+
 // split-K form of vmtl_conv2d_fwd for plain contractions (no bias / act / stats / shuffle): `ws` holds
 // vmtl_conv2d_ksplit(...) * B*Ho*Wo*ldy floats.  With ksplit == 1 it is exactly vmtl_conv2d_fwd.
 extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int B, int H, int W, int Cs,
@@ -992,7 +1109,7 @@ extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, flo
   p.x = x; p.wp = wp; p.bias = nullptr; p.y = ws; p.stats = nullptr; p.x2 = nullptr; p.C2s = 0;
   p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
-  p.act = 0; p.shuffle = 0;
+  p.act = 0; p.shuffle = 0; p.ez_x = nullptr; p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = nullptr; p.ez_act = 0;
   p.ksplit = splits;
   p.ksteps_per_split = cdiv(cdiv(p.Ktot, BK), splits);
   hipStream_t st = (hipStream_t)stream;
@@ -1057,6 +1174,7 @@ extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const flo
   p.B = B; p.H = H2; p.W = W2; p.Cs = C0s; p.C2s = C1s; p.Ho = H2; p.Wo = W2; p.ldy = ldy; p.Nw = Cout;
   p.Cout = Cout; p.KH = 2; p.KW = 2; p.stride = 1; p.pad = 0; p.Ktot = 4 * C0s + 9 * C1s; p.M = B * H2 * W2;
   p.act = 0; p.shuffle = 0; p.ksplit = 1; p.ksteps_per_split = 0;
+  p.ez_x = nullptr; p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = nullptr; p.ez_act = 0;
   const int id = up2_pick_tile(p.M, ldy);
   if (stats && (p.M % kTiles[id].bm)) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

@@ -65,6 +65,8 @@ struct SmallP {
   int act_in, ep_mode, ez_act, Ca;
   int B, H, W, ldy, Nw, Cout;
   int tiles_x, tiles_y, ntiles;
+  int grid;      // workgroups (persistent: each walks tiles grid apart)
+  int acc_rows;  // statistics: 1 = one row per WORKGROUP (accumulated over its tiles), 0 = one row per tile
   int dbg;  // tuning aid (VMTL_SMALL_DBG): 1 skip the output stores, 2 skip halo staging, 4 skip the MFMA loop, 8 no start skew
 };
 
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __builtin_amdgcn_s_sleep(40);
     }
   }
+  // statistics accumulated over this workgroup's tiles (threads tid < SQ own one channel quad each)
+  f32x4 wg_a = {0.f, 0.f, 0.f, 0.f}, wg_c = wg_a;
+  float wg_n = 0.f;
   int t = blockIdx.x;
   int nb = 0, nh0 = 0, nw0 = 0;
   if (t < p.ntiles) {
@@ -463,8 +468,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int w = 0; w < 4; ++w)
 #pragma unroll
             for (int q = 0; q < PPI; ++q) c += red[256 + w * 64 + q * SQ + tid];
-          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = m;  // tid == eq for these lanes
-          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
+          if (p.acc_rows) {  // Chan's merge of (count, mean, M2) with the tiles seen so far
+            constexpr float nt = (float)(CSM_TH * CSM_TW);
+            const f32x4 d = m - wg_a;
+            wg_a += d * (nt / (wg_n + nt));
+            wg_c += c + d * d * (wg_n * nt / (wg_n + nt));
+            wg_n += nt;
+          } else {
+            *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = m;  // tid == eq for these lanes
+            *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
+          }
         }
       } else if (tid < SQ && 4 * tid < p.ldy) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
@@ -475,16 +488,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a += red[w * 64 + q * SQ + tid];
             c += red[256 + w * 64 + q * SQ + tid];
           }
-        *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = a;
-        *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
+        if (p.acc_rows) {
+          wg_a += a;
+          wg_c += c;
+        } else {
+          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = a;
+          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
+        }
       }
     }
   }
+  if (p.ep_mode != 0 && p.acc_rows && tid < SQ && 4 * tid < p.ldy) {
+    *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + 4 * tid) = wg_a;
+    *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + 4 * tid) = wg_c;
+  }
 }
-
 
 // ---------------------------------------------------------------------------------------------- launch
 int small_cus();
+int small_grid(int ntiles, int* acc_rows);
 
 template <int CS, int TN, int NT, bool X2>
 static int launch_small_x(SmallP& p, hipStream_t st) {
@@ -494,9 +516,9 @@ static int launch_small_x(SmallP& p, hipStream_t st) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<CS, TN, NT, X2>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
     return VMTL_ERR_LAUNCH;
-  const int per_cu = C::LDS_BYTES * 2 <= 160 * 1024 ? 2 : 1;
-  int grid = small_cus() * ((p.dbg & 64) ? 1 : per_cu);
-  if (grid > p.ntiles) grid = p.ntiles;
+  static_assert(C::LDS_BYTES * 2 <= 160 * 1024, "two workgroups per CU (small_grid() assumes it)");
+  int grid = p.grid;
+  if (p.dbg & 64) grid = small_cus() < p.ntiles ? small_cus() : p.ntiles;  // tuning aid: one workgroup per CU
   hipLaunchKernelGGL((conv3x3_small_kernel<CS, TN, NT, X2>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
   return vmtl_check_launch();
 }

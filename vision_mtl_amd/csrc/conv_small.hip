@@ -19,6 +19,29 @@ int small_cus() {
   return n;
 }
 
+// Persistent grid: two workgroups per CU.  With a statistics epilogue every workgroup must see the same number of
+// tiles (the BatchNorm finalize weights all rows equally), so the grid is the largest divisor of the tile count that
+// still fills at least half the slots; a workgroup then ACCUMULATES its tiles into one statistics row (512 rows
+// instead of 8192 for 32 x 128 x 256: the one-workgroup-per-channel finalize kernels took 33 us on 8192 rows).
+// Shapes without such a divisor keep one row per tile.
+int small_grid(int ntiles, int* acc_rows) {
+  const int slots = 2 * small_cus();
+  int best = 0;
+  for (int g = slots < ntiles ? slots : ntiles; g >= 1; --g)
+    if (ntiles % g == 0) { best = g; break; }
+  if (acc_rows) *acc_rows = 0;
+  static int allow = -1;  // VMTL_SMALL_ACC=0: tuning aid, one statistics row per tile
+  if (allow < 0) {
+    const char* e = getenv("VMTL_SMALL_ACC");
+    allow = e ? atoi(e) : 1;
+  }
+  if (allow && best * 2 >= (slots < ntiles ? slots : ntiles)) {
+    if (acc_rows) *acc_rows = 1;
+    return best;
+  }
+  return slots < ntiles ? slots : ntiles;
+}
+
 // 1 when vmtl_conv3x3_small handles a 3x3/s1/p1 conv with Cs input storage channels and Nw weight rows
 extern "C" int vmtl_conv3x3_small_supported(int Cs, int Nw) {
   return (Cs == 20 || Cs == 36 || Cs == 32 || Cs == 16) && Nw >= 1 && Nw <= 36;
@@ -26,6 +49,19 @@ extern "C" int vmtl_conv3x3_small_supported(int Cs, int Nw) {
 
 // statistics rows (= tiles); the statistics epilogues need full tiles: H % 4 == 0 and W % 32 == 0
 extern "C" int vmtl_conv3x3_small_tiles(int B, int H, int W) { return B * cdiv(H, CSM_TH) * cdiv(W, CSM_TW); }
+
+// rows of the statistics tensor [rows][2][ldy] written by ep_mode 1 / 2, and the pixels each row covers
+extern "C" int vmtl_conv3x3_small_stat_rows(int B, int H, int W) {
+  int acc = 0;
+  const int nt = vmtl_conv3x3_small_tiles(B, H, W), g = small_grid(nt, &acc);
+  return acc ? g : nt;
+}
+
+extern "C" int vmtl_conv3x3_small_stat_block(int B, int H, int W) {
+  int acc = 0;
+  const int nt = vmtl_conv3x3_small_tiles(B, H, W), g = small_grid(nt, &acc);
+  return CSM_TH * CSM_TW * (acc ? nt / g : 1);
+}
 
 extern "C" int vmtl_conv3x3_small(const float* x, const float* x2, const float* pa, const float* pb, const float* pc,
                                   int act_in, float* a_out, const float* wp, const float* bias, float* y, float* yb,
@@ -49,6 +85,7 @@ extern "C" int vmtl_conv3x3_small(const float* x, const float* x2, const float* 
   p.act_in = act_in; p.ep_mode = ep_mode; p.ez_act = ez_act; p.Ca = Ca;
   p.B = B; p.H = H; p.W = W; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.tiles_x = cdiv(W, CSM_TW); p.tiles_y = cdiv(H, CSM_TH); p.ntiles = B * p.tiles_x * p.tiles_y;
+  p.grid = small_grid(p.ntiles, &p.acc_rows);
   const char* dbg = getenv("VMTL_SMALL_DBG");
   p.dbg = dbg ? atoi(dbg) : 0;
   hipStream_t st = (hipStream_t)stream;

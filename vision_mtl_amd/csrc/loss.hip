@@ -71,11 +71,11 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restr
                                                             const long long* __restrict__ tgt,
                                                             const float* __restrict__ gout, float* __restrict__ dz,
                                                             long long P, int HW, int C, long long sb, long long sc,
-                                                            long long sp) {
+                                                            long long sp, long long dsb, long long dsc, long long dsp) {
   const float g = gout[0] / (float)P;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / HW, hw = i - b * HW;
-    const long long off = b * sb + hw * sp;
+    const long long off = b * sb + hw * sp, doff = b * dsb + hw * dsp;
     float m = z[off];
     for (int c = 1; c < C; ++c) m = fmaxf(m, z[off + c * sc]);
     float s = 0.f;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restr
     const float inv = 1.f / s;
     const long long t = tgt[i];
     const float bad = (t < 0 || t >= C) ? __int_as_float(0x7fc00000) : 0.f;  // as the forward: NaN, never a silent 0
-    for (int c = 0; c < C; ++c) dz[off + c * sc] = (expf(z[off + c * sc] - m) * inv - (c == t ? 1.f : 0.f)) * g + bad;
+    for (int c = 0; c < C; ++c) dz[doff + c * dsc] = (expf(z[off + c * sc] - m) * inv - (c == t ? 1.f : 0.f)) * g + bad;
   }
 }
 
@@ -120,7 +120,21 @@ extern "C" int vmtl_ce_bwd(const float* logits, const long long* target, const f
   if (!logits || !target || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   const long long P = (long long)B * HW;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target,
-                     grad_out, dlogits, P, HW, C, sb, sc, sp);
+                     grad_out, dlogits, P, HW, C, sb, sc, sp, sb, sc, sp);
+  return vmtl_check_launch();
+}
+
+// vmtl_ce_bwd with its own strides for dlogits: element (b, c, hw) of the gradient goes to dlogits[b*dsb + c*dsc +
+// hw*dsp].  With (HW*ld, 1, ld) the gradient lands in the NHWC storage the head's data-gradient conv reads (one
+// 76-byte run per pixel) and the NCHW -> NHWC relayout of an 80 MB tensor disappears from the step.
+extern "C" int vmtl_ce_bwd_strided(const float* logits, const long long* target, const float* grad_out, float* dlogits,
+                                   int B, int HW, int C, long long sb, long long sc, long long sp, long long dsb,
+                                   long long dsc, long long dsp, void* stream) {
+  VMTL_ENTER();
+  if (!logits || !target || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
+  const long long P = (long long)B * HW;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target,
+                     grad_out, dlogits, P, HW, C, sb, sc, sp, dsb, dsc, dsp);
   return vmtl_check_launch();
 }
 

@@ -249,15 +249,32 @@ class UnetDecoder(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def run(self, feats: t.List[L.Act], raw_tail: bool = False):
-        """raw_tail: stop after conv1 of the LAST block and return DecoderBlock.run_conv1_raw's triple."""
+        """The decoder as a chain of PRE-activation nodes: every conv hands its raw output (+ BatchNorm partial rows
+        from its epilogue) to the next node, which owns that BatchNorm + ReLU together with its own conv
+        (ops.bn_act_conv) so that the backward pass can fuse them.
+        raw_tail: stop after conv1 of the LAST block and return (raw output, its statistics rows, pixels per row) -
+        the caller continues with ops.decoder_tail."""
         feats = feats[1:][::-1]
         x, skips = feats[0], feats[1:]
+        ops = L.ops
+        raw = st = None
+        rpb, bn, C = 0, None, 0
         for i, blk in enumerate(self.blocks):
             skip = skips[i] if i < len(skips) else None
+            c1, bn1, c2, bn2 = blk.conv1[0], blk.conv1[1], blk.conv2[0], blk.conv2[1]
+            skt = None if skip is None else skip.t
+            if raw is None:  # first block: its input is an (already activated) encoder feature
+                raw, st, rpb = blk.run_conv1_raw(x, skip)
+                raw = raw.t
+            else:
+                raw, st, rpb = ops.bn_act_conv(raw, st, rpb, bn, C, ACT_RELU, c1.weight, skip=skt, up2=True,
+                                               want_stats=bn1.training)
+            bn, C = bn1, c1.out_channels
             if raw_tail and i == len(self.blocks) - 1:
-                return blk.run_conv1_raw(x, skip)
-            x = blk.run(x, skip)
-        return x
+                return L.Act(raw, C), st, rpb
+            raw, st, rpb = ops.bn_act_conv(raw, st, rpb, bn, C, ACT_RELU, c2.weight, want_stats=bn2.training)
+            bn, C = bn2, c2.out_channels
+        return L.bn_act(L.Act(raw, C), bn, ACT_RELU, stats=st)
 
 
 class Activation(nn.Module):

@@ -526,6 +526,182 @@ class _Up2Conv(torch.autograd.Function):
         return dxl, dskip, dw, None, None
 
 
+class _BNActConv(torch.autograd.Function):
+    """(y, stats) = conv3x3(act(BN(x)))   or, with up2,   conv3x3(cat[nearest_x2(act(BN(x))), skip])
+    - one smp `Conv2dReLU` boundary (reference utils/model_utils.py:25-34, 72-76) taken in PRE-activation form:
+    x is the RAW output of the previous conv (stats = its BatchNorm partial rows from the conv epilogue, rpb pixels
+    each), y the raw output of this one.  Owning BatchNorm+activation AND the consuming conv in one autograd node
+    lets the backward pass fuse them: the data gradient of the conv ends with the activation + BatchNorm backward of
+    its own input (dz and its per-row-block column sums come out of the implicit GEMM's epilogue,
+    vmtl_conv2d_bnbwd), so the BatchNorm backward keeps only its finalize and apply launches - no reduce pass."""
+
+    @staticmethod
+    def forward(ctx, x, stats, rpb, gamma, beta, rm, rv, nbt, weight, skip, cfg):
+        C, training, momentum, eps, act, up2, want_stats = cfg
+        x, weight = _req(x, "x"), _req(weight, "weight")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if ceil4(C) != Cs or tuple(weight.shape[2:]) != (3, 3):
+            raise ValueError("bn_act_conv: 3x3 weight over x's channels expected")
+        # ---- BatchNorm + activation (materialised: the weight gradient reads it)
+        mean, invstd = _empty((Cs,), x), _empty((Cs,), x)
+        a = _empty(x.shape, x)
+        if training:
+            if stats is not None:
+                partial, nblk = stats, stats.shape[0]
+            else:
+                partial, nblk, rpb = _empty((_reduce_rows(M), 2, Cs), x), 0, 0
+            if 0 < nblk <= _BN_FUSE_ROWS:
+                _k("vmtl_bn_apply_fused", x=x, partial=partial, nblk=nblk, rows_per_blk=rpb, eps=eps, momentum=momentum,
+                   running_mean=rm, running_var=rv, num_batches_tracked=nbt, save_mean=mean, save_invstd=invstd,
+                   gamma=gamma, beta=beta, mul=None, res=None, y=a, M=M, C=C, Cs=Cs, act=act)
+            else:
+                _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk, rows_per_blk_from_conv=rpb,
+                   eps=eps, momentum=momentum, running_mean=rm, running_var=rv, num_batches_tracked=nbt, save_mean=mean,
+                   save_invstd=invstd)
+                _k("vmtl_bn_apply", x=x, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=None, res=None, y=a, M=M,
+                   C=C, Cs=Cs, act=act)
+        else:
+            _k("vmtl_bn_eval_stats", running_mean=rm, running_var=rv, C=C, Cs=Cs, eps=eps, save_mean=mean, save_invstd=invstd)
+            _k("vmtl_bn_apply", x=x, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=None, res=None, y=a, M=M, C=C,
+               Cs=Cs, act=act)
+        # ---- the conv on a
+        ldy = ceil4(Cout)
+        ostats, orpb = None, 0
+        if up2:
+            if skip is not None:
+                skip = _req(skip, "skip")
+                C1s = skip.shape[3]
+                if tuple(skip.shape[:3]) != (B, 2 * H, 2 * W):
+                    raise ValueError("bn_act_conv(up2): skip must be at twice the resolution of x")
+            else:
+                C1s = 0
+            C1 = Cin - C
+            if ceil4(C1) != C1s or (C1 > 0) != (skip is not None):
+                raise ValueError("bn_act_conv(up2): weight channels do not match x + skip")
+            Ktot = 4 * Cs + 9 * C1s
+            wp = packs.get_custom(weight, "up2_fwd", (4, Cout, Ktot), lambda w, dst: _k(
+                "vmtl_pack_up2_fwd", w=w, dst=dst, Cout=Cout, C0=C, C0s=Cs, C1=C1, C1s=C1s))
+            y = _empty((B, 2 * H, 2 * W, ldy), x)
+            if want_stats:
+                bm = lib().raw("vmtl_conv2d_up2_stats_block")(B, H, W, ldy)
+                if M % bm == 0:
+                    ostats, orpb = _empty((4 * (M // bm), 2, ldy), x), bm
+            Mo = 4 * M
+            _k("vmtl_conv2d_up2_fwd", _flop=2.0 * Mo * Cout * 9 * Cin, _xflop=2.0 * Mo * Cout * (4 * C + 9 * C1), xl=a,
+               skip=skip, wp_eff=wp, y=y, stats=ostats, B=B, H2=H, W2=W, C0s=Cs, C1s=C1s, ldy=ldy, Cout=Cout)
+        else:
+            if Cin != C or skip is not None:
+                raise ValueError("bn_act_conv: weight expects x's channels (skip only with up2)")
+            wp = packs.get(weight, "fwd", (1, Cout, 9, Cin, Cs, 0, Cin * 9, 1, 9, 0))
+            y = _empty((B, H, W, ldy), x)
+            if want_stats:
+                ostats = _empty((lib().raw("vmtl_conv2d_stats_rows")(B, H, W, ldy), 2, ldy), x)
+                orpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, ldy)
+            _conv_launch(a, wp, None, y, ostats, B, H, W, Cs, H, W, ldy, Cout, Cout, 3, 3, 1, 1, cin=Cin)
+        ctx.save_for_backward(x, a, skip, weight, mean, invstd, gamma, beta)
+        ctx.cfg = (C, training, act, up2)
+        ctx.slots = (_slot(gamma), _slot(beta), _slot(weight))
+        ctx.orpb = orpb
+        ctx.set_materialize_grads(False)
+        if ostats is not None:
+            ctx.mark_non_differentiable(ostats)
+        return y, ostats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, a, skip, weight, mean, invstd, gamma, beta = ctx.saved_tensors
+        C, training, act, up2 = ctx.cfg
+        sg, sb, sw = ctx.slots
+        if dy is None:
+            return (None,) * 11
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        ldy = dy.shape[3]
+        stamp(f"main bnconv M={dy.shape[0] * dy.shape[1] * dy.shape[2]} N={Cout} Cin={Cin}")
+        fork = side.mark()
+        # ---- data gradient w.r.t. a = act(BN(x)), with act' and the BatchNorm-backward column sums in the epilogue
+        if up2:
+            Hd, Wd = 2 * H, 2 * W  # dy's extent
+            wd = packs.get_custom(weight, "up2_dgrad", (C, 16 * ldy), lambda w, dst: _k(
+                "vmtl_pack_up2_dgrad", w=w, dst=dst, Cout=Cout, Cos=ldy, C0=C, Cin=Cin))
+            geo = dict(B=B, H=Hd, W=Wd, Cs=ldy, Ho=H, Wo=W, ldy=Cs, Nw=C, Cout=C, KH=4, KW=4, stride=2, pad=1)
+            flop, xflop = 2.0 * B * Hd * Wd * C * 9 * Cout, 2.0 * M * C * 16 * Cout
+        else:
+            Hd, Wd = H, W
+            wd = packs.get(weight, "dgrad", (1, Cin, 9, Cout, ldy, 0, 9, 1, Cin * 9, 1))
+            geo = dict(B=B, H=H, W=W, Cs=ldy, Ho=H, Wo=W, ldy=Cs, Nw=Cin, Cout=Cin, KH=3, KW=3, stride=1, pad=1)
+            flop = xflop = 2.0 * M * Cin * 9 * Cout
+        dgamma = _empty((C,), x) if sg is None else sg
+        dbeta = _empty((C,), x) if sb is None else sb
+        dx = _empty(x.shape, x) if ctx.needs_input_grad[0] else None
+        fuse = lib().raw("vmtl_conv2d_ksplit")(B, H, W, Cs, geo["KH"] * geo["KW"] * ldy) <= 1 \
+            and os.environ.get("VMTL_BNBWD_FUSE", "1") != "0"
+        if fuse:
+            dz = _empty(x.shape, x)
+            rows = lib().raw("vmtl_conv2d_stats_rows")(B, H, W, Cs)
+            part = _empty((rows, 2, Cs), x)
+            _k("vmtl_conv2d_bnbwd", _flop=flop, _xflop=xflop, x=dy, wp=wd, y=dz, stats=part, ez_x=x, ez_mean=mean,
+               ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, **geo)
+            _k("vmtl_bn_bwd_finalize", partial=part, nblk=rows, M=M, C=C, Cs=Cs, sum_dz=dbeta, sum_dzx=dgamma, mean=None,
+               invstd=None, gamma=None, training=1 if training else 0, coef_a=None, coef_b=None, coef_c=None)
+            if dx is not None:
+                _k("vmtl_bn_bwd_apply", x=x, dz=dz, mean=mean, invstd=invstd, gamma=gamma, sum_dz=dbeta, sum_dzx=dgamma,
+                   dx=dx, M=M, C=C, Cs=Cs, training=1 if training else 0)
+        else:  # split-K data gradient (tile-starved layers): unfused BatchNorm backward
+            da = _empty(x.shape, x)
+            _conv_launch(dy, wd, None, da, None, geo["B"], geo["H"], geo["W"], geo["Cs"], geo["Ho"], geo["Wo"], geo["ldy"],
+                         geo["Nw"], geo["Cout"], geo["KH"], geo["KW"], geo["stride"], geo["pad"], cin=Cout, algo_flop=flop)
+            part = _empty((_reduce_rows(M), 2, Cs), x)
+            _k("vmtl_bn_bwd", x=x, dy=da, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=None, dmul=None,
+               partial=part, sum_dz=dbeta, sum_dzx=dgamma, dx=dx if dx is not None else _empty(x.shape, x), M=M, C=C, Cs=Cs,
+               act=act, training=1 if training else 0)
+        dskip = None
+        if up2 and skip is not None and ctx.needs_input_grad[9]:
+            C1, C1s = Cin - C, skip.shape[3]
+            wds = packs.get(weight, "up2_dskip", (1, C1, 9, Cout, ldy, 0, 9, 1, Cin * 9, 1), offset=C * 9)
+            dskip = _empty(skip.shape, x)
+            _conv_launch(dy, wds, None, dskip, None, B, Hd, Wd, ldy, Hd, Wd, C1s, C1, C1, 3, 3, 1, 1, cin=Cout)
+        # ---- weight gradient (side stream when it goes to an arena slot)
+        dw = _empty(weight.shape, x) if sw is None else sw
+        with side.branch(sw is not None, B * Hd * Wd, fork, dy, a, skip):
+            if up2:
+                slabs, ns = _wgrad(dy, a, B, Hd, Wd, ldy, H, W, Cs, C, 4, 4, 2, 1, 2.0 * B * Hd * Wd * Cout * 9 * C,
+                                   xflop=2.0 * M * C * 16 * Cout)
+                _k("vmtl_unpack_up2", slabs=slabs, grad=dw, Cout=Cout, Cos=ldy, C0=C, Cin=Cin, nslabs=ns)
+                if skip is not None:
+                    C1, C1s = Cin - C, skip.shape[3]
+                    slabs, ns = _wgrad(skip, dy, B, Hd, Wd, C1s, Hd, Wd, ldy, Cout, 3, 3, 1, 1,
+                                       2.0 * B * Hd * Wd * Cout * 9 * C1)
+                    unpack(slabs, None, 1, Cout, 9, C1, C1s, 0, Cin * 9, 1, 9, out=dw.view(-1)[C * 9:], nslabs=ns)
+            else:
+                slabs, ns = _wgrad(a, dy, B, H, W, Cs, H, W, ldy, Cout, 3, 3, 1, 1, 2.0 * M * Cout * 9 * Cin)
+                unpack(slabs, weight.shape, 1, Cout, 9, Cin, Cs, 0, Cin * 9, 1, 9, out=dw, nslabs=ns)
+            stamp(f"side bnconv N={Cout} Cin={Cin}")
+        nif = lambda g, slot: None if slot is not None else g
+        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), dskip, None
+
+
+def bn_act_conv(x, stats, rpb, bn, C, act, weight, skip=None, up2=False, want_stats=True):
+    """(y_raw, stats, rows_per_block) = conv3x3(act(bn(x_raw)))  (up2: nearest-x2 of it, concatenated with skip, first);
+    bn is the nn.BatchNorm2d parameter container of x's layer, C its logical channel count."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
+    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, bool(up2), bool(want_stats))
+    y, ostats = _BNActConv.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                 bn.num_batches_tracked, weight, skip, cfg)
+    orpb = 0
+    if ostats is not None:
+        B, H, W, _ = x.shape
+        ldy = y.shape[3]
+        orpb = (lib().raw("vmtl_conv2d_up2_stats_block")(B, H, W, ldy) if up2
+                else lib().raw("vmtl_conv2d_stats_block")(B, H, W, ldy))
+    return y, ostats, orpb
+
+
 def up2_conv(xl, C0, skip, weight, want_stats=False):
     """(y, stats) = conv3x3(cat[nearest_x2(xl), skip]); C0 = logical channels of xl; stats may be None."""
     return _Up2Conv.apply(xl, skip, weight, C0, want_stats)
@@ -1136,7 +1312,8 @@ class _DecoderTail(torch.autograd.Function):
             raise ValueError("decoder_tail: shape not covered by vmtl_conv3x3_small (use decoder_tail_supported())")
         need_bwd = any(ctx.needs_input_grad)
         M = B * H * W
-        tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
+        tiles = lib().raw("vmtl_conv3x3_small_stat_rows")(B, H, W)  # statistics rows ...
+        rpb = lib().raw("vmtl_conv3x3_small_stat_block")(B, H, W)   # ... of this many pixels each
         mean1, invstd1, pa1, pc1 = _bn_fwd_coef(x1, stats1, rpb1, g1, b1, rm1, rv1, nbt1, C1, tr1, mom1, eps1)
         wp2 = packs.get(w2, "fwd", (1, C2, 9, C1, Cs1, 0, C1 * 9, 1, 9, 0))
         a1 = _empty(x1.shape, x1) if need_bwd else None
@@ -1144,7 +1321,7 @@ class _DecoderTail(torch.autograd.Function):
         stats2 = _empty((tiles, 2, ldy2), x1) if tr2 else None
         _small(x1, wp2, x2, B, H, W, Cs1, ldy2, C2, C2, 2.0 * M * C2 * 9 * C1, pa=pa1, pc=pc1, act_in=ACT_RELU, a_out=a1,
                stats=stats2, ep_mode=1 if tr2 else 0)
-        mean2, invstd2, pa2, pc2 = _bn_fwd_coef(x2, stats2, 128, g2, b2, rm2, rv2, nbt2, C2, tr2, mom2, eps2)
+        mean2, invstd2, pa2, pc2 = _bn_fwd_coef(x2, stats2, rpb, g2, b2, rm2, rv2, nbt2, C2, tr2, mom2, eps2)
         wph = _empty((N, 9 * ldy2), x1)
         pack(wa, 1, Ca, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=wph[:Ca])
         pack(wb, 1, Cb, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=wph[Ca:])
@@ -1171,12 +1348,18 @@ class _DecoderTail(torch.autograd.Function):
         N = Ca + Cb
         ldy2, ldyh = ceil4(C2), ceil4(N)
         M = B * H * W
-        tiles = lib().raw("vmtl_conv3x3_small_tiles")(B, H, W)
-        ga = torch.zeros((B, Ca, H, W), device=x1.device) if ga is None else _req(ga, "grad a")
+        tiles = lib().raw("vmtl_conv3x3_small_stat_rows")(B, H, W)
         gb = torch.zeros((B, Cb, H, W), device=x1.device) if gb is None else _req(gb, "grad b")
-        dy = _empty((B, H, W, ldyh), x1)
+        # head a's gradient may already sit in NHWC storage of the right width (the cross-entropy backward writes it so)
+        dy = None
+        if ga is not None and ga.stride() == (H * W * ldyh, 1, W * ldyh, ldyh) and ga.storage_offset() == 0 \
+                and ga.dtype == torch.float32 and ga.untyped_storage().nbytes() == 4 * B * H * W * ldyh:
+            dy = torch.as_strided(ga, (B, H, W, ldyh), (H * W * ldyh, W * ldyh, ldyh, 1))
+        if dy is None:
+            ga = torch.zeros((B, Ca, H, W), device=x1.device) if ga is None else _req(ga, "grad a")
+            dy = _empty((B, H, W, ldyh), x1)
+            _k("vmtl_nchw_to_nhwc", x=ga, y=dy.view(-1), B=B, C=Ca, HW=H * W, Cs=ldyh, Cw=Ca)
         dyf = dy.view(-1)
-        _k("vmtl_nchw_to_nhwc", x=ga, y=dyf, B=B, C=Ca, HW=H * W, Cs=ldyh, Cw=Ca)
         _k("vmtl_nchw_to_nhwc", x=gb, y=dyf[Ca:], B=B, C=Cb, HW=H * W, Cs=ldyh, Cw=ldyh - Ca)  # also zeroes pad lanes
         stamp("main tail heads")
         fork = side.mark()
@@ -1397,9 +1580,15 @@ class _CrossEntropy(torch.autograd.Function):
         logits, target = ctx.saved_tensors
         B, C, H, W = logits.shape
         g = _req(g, "grad_output")
-        dl = _empty(logits.shape, logits)
-        _k("vmtl_ce_bwd", logits=logits, target=target, grad_out=g, dlogits=dl, B=B, HW=H * W, C=C,
-           sb=C * H * W, sc=H * W, sp=1)
+        # the gradient is laid out NHWC with room for one more head ([B][H][W][ceil4(C+1)]) and returned as its
+        # (B,C,H,W) view: a head conv that consumes it (ops.decoder_tail) takes the storage as its dY operand without
+        # the NCHW -> NHWC relayout of this 80 MB tensor; any other consumer sees an ordinary strided tensor
+        ld = ceil4(C + 1)
+        st = _empty((B, H, W, ld), logits)
+        _k("vmtl_ce_bwd_strided", logits=logits, target=target, grad_out=g, dlogits=st, B=B, HW=H * W, C=C,
+           sb=C * H * W, sc=H * W, sp=1, dsb=H * W * ld, dsc=1, dsp=ld)
+        dl = st[..., :C].permute(0, 3, 1, 2)
+        dl._vmtl_nhwc = st
         return dl, None
 
 
