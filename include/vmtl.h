@@ -54,6 +54,16 @@ int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
 int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
 
+/* Pointwise (1x1 / stride 1) conv as a plain GEMM y[M][ldy] = x[M][Ks] * wp[Nw][Ks]^T (+ bias) for small problems on a
+ * dependent chain (timm pointwise convs via utils/model_utils.py:25-34; models/mtan_model.py:31,39,105,113,369):
+ * fragments straight from global memory, K split over the waves of a workgroup when the tile grid is small
+ * (csrc/conv_pw.hip).  stats (optional): [vmtl_conv1x1_stats_rows][2][ldy] per-row-block (mean, M2) of y,
+ * vmtl_conv1x1_stats_block rows each. */
+int vmtl_conv1x1_stats_block(int M, int ldy, int Ks);
+int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks);
+int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,
+                     int Nw, int Cout, void* stream);
+
 /* vmtl_conv2d_fwd used as a DATA GRADIENT with the BatchNorm + activation backward of the layer that produced the
  * differentiated tensor fused into the epilogue (reference utils/model_utils.py:72-76 run backwards): y = conv *
  * act'(ez_gamma*xhat + ez_beta), xhat = (ez_x - ez_mean)*ez_invstd; stats[vmtl_conv2d_stats_rows(B,Ho,Wo,ldy)][2][ldy] =

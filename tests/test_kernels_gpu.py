@@ -66,7 +66,7 @@ def test_conv2d_fwd_bwd(dev, case):
 
     Ho, Wo = yr.shape[2], yr.shape[3]
     M = B * Ho * Wo
-    rpb = lib().raw("vmtl_conv2d_stats_block")(B, Ho, Wo, y.shape[-1])
+    rpb = stats._vmtl_rpb  # pixels per statistics row (the launch's row block: implicit GEMM or pointwise kernel)
     st = stats.double().cpu()
     nb = torch.tensor([max(0, min(rpb, M - b * rpb)) for b in range(st.shape[0])], dtype=torch.float64)[:, None]
     mean = (nb * st[:, 0]).sum(0) / M

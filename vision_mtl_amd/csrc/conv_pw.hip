@@ -1,0 +1,222 @@
+// Pointwise (1x1, stride 1) convolution = plain GEMM  Y[M][ldy] = X[M][Ks] * Wp[Nw][Ks]^T  for the MobileNetV3
+// encoder's expand / project convs (timm pointwise convs of the `basic` / `csnet` encoders, reference
+// vision_mtl/utils/model_utils.py:25-34) and the 1x1 convs of MTAN's attention modules (reference
+// models/mtan_model.py:31,39,105,113,369), forward and data gradient (the data gradient of a 1x1 conv is the same
+// GEMM over dY with the transposed packing).
+//
+// Why not the implicit-GEMM kernel (conv_igemm.hip): these launches are SMALL (M = B*H*W <= 262144, K = 16..960,
+// N = 16..960; 0.03-0.6 GFLOP) and sit on a dependent chain.  There they measured 12-50 us each - a floor of ~12 us
+// from the LDS-staged pipeline (global -> registers -> LDS -> barrier -> fragments, plus three barriers of statistics
+// epilogue), and K-latency-bound above it when M*N yields fewer workgroups than CUs (each K step then pays a full
+// global-load latency for a few MFMAs).  Here:
+//   * no LDS in the K loop and no barrier: every wave loads its own MFMA fragments straight from global memory /
+//     L2 (rows are K-contiguous: a lane reads 16 bytes, the four lane quarters of a row read one 64-byte segment),
+//     two k-groups in flight;
+//   * when the tile grid alone cannot fill the chip the four waves of a workgroup SPLIT K (KW = 4) and combine
+//     through LDS once at the end - 4x the waves for the tile-starved deep layers (M = 1024 / 4096);
+//   * the output tile goes through LDS so that y is written as coalesced float4 rows, with the bias add and the
+//     BatchNorm (mean, M2) partials of the tile taken on the way.
+#include "common.h"
+
+struct PwP {
+  const float* x;     // [M][Ks]
+  const float* wp;    // [Nw][Ks]
+  const float* bias;  // [Nw] or null
+  float* y;           // [M][ldy]
+  float* stats;       // optional [tiles_m][2][ldy]: per-row-block column (mean, M2)
+  int M, Ks, ldy, Nw, Cout;
+  int tiles_m, tiles_n;
+};
+
+// wave tile 32 rows x (16*TN) columns; KW waves of the workgroup split K, the other 4/KW stack along M
+template <int TN, int KW>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
+  constexpr int TM = 2;
+  constexpr int RG = 4 / KW;        // row groups (waves along M)
+  constexpr int BM = RG * 32;       // rows per workgroup
+  constexpr int BN = 16 * TN;       // columns per workgroup
+  constexpr int OS = BN + 4;        // LDS row stride (floats): = 4 (mod 8) -> conflict-free ds_write_b32 from the C layout
+  __shared__ __attribute__((aligned(16))) float tile[KW][BM][OS];
+  __shared__ f32x4 red[2][256];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int ks = wv % KW, rg = wv / KW;
+  const int bid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // fragment sources: A rows m0 + rg*32 + 16 i + l15, B rows n0 + 16 j + l15; k = 16 g + 4 lq .. + 3
+  const float* ap[TM];
+  const float* bp[TN];
+  bool aok[TM], bok[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + rg * 32 + 16 * i + l15;
+    aok[i] = m < p.M;
+    ap[i] = p.x + (size_t)(aok[i] ? m : 0) * p.Ks + 4 * lq;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + 16 * j + l15;
+    bok[j] = n < p.Nw;
+    bp[j] = p.wp + (size_t)(bok[j] ? n : 0) * p.Ks + 4 * lq;
+  }
+  const int G = (p.Ks + 15) >> 4;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  struct Frag { f32x4 a[TM], b[TN]; };
+  auto load = [&](int g, Frag& f) {
+    const bool kok = g < G && 16 * g + 4 * lq < p.Ks;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      f.a[i] = (kok && aok[i]) ? *reinterpret_cast<const f32x4*>(ap[i] + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      f.b[j] = (kok && bok[j]) ? *reinterpret_cast<const f32x4*>(bp[j] + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+  };
+  // this wave's k-groups: ks, ks + KW, ...; three in flight
+  Frag f0, f1, f2;
+  int g = ks;
+  load(g, f0);
+  load(g + KW, f1);
+  for (; g < G; g += 3 * KW) {
+    load(g + 2 * KW, f2);
+    mma(f0);
+    if (g + KW >= G) break;
+    load(g + 3 * KW, f0);
+    mma(f1);
+    if (g + 2 * KW >= G) break;
+    load(g + 4 * KW, f1);
+    mma(f2);
+  }
+
+  // ---- C layout -> LDS (one plane per K slice); C: column = lane & 15, row = 4 * (lane >> 4) + reg ----
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[ks][rg * 32 + 16 * i + 4 * lq + r][16 * j + l15] = acc[i][j][r];
+  __syncthreads();
+
+  // ---- epilogue: thread <-> (row, column quad); K slices summed, bias, coalesced float4 stores, statistics ----
+  constexpr int Q = BN / 4;            // quads per row
+  constexpr int RPP = 256 / Q;         // rows per pass
+  constexpr int PASSES = (BM + RPP - 1) / RPP;
+  const int q = tid % Q, r0 = tid / Q;
+  const int n4 = n0 + 4 * q;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n4 + e < p.Nw) bias4[e] = p.bias[n4 + e];
+  }
+  f32x4 val[PASSES];
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int r = r0 + ps * RPP;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < BM) {
+      v = *reinterpret_cast<const f32x4*>(&tile[0][r][4 * q]);
+#pragma unroll
+      for (int k = 1; k < KW; ++k) v += *reinterpret_cast<const f32x4*>(&tile[k][r][4 * q]);
+      v += bias4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n4 + e >= p.Cout) v[e] = 0.f;
+      const int m = m0 + r;
+      if (m < p.M) {
+        if (n4 < p.ldy) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n4) = v;
+        s1 += v;
+        ++cnt;
+      } else {
+        v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    val[ps] = v;
+  }
+  if (p.stats != nullptr) {
+    // per-tile (mean, M2) of every column: rows of a column live in the RPP threads tid = q + Q * r0
+    const int nvalid = min(BM, p.M - m0);
+    red[0][tid] = s1;
+    __syncthreads();
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < RPP; ++k) m += red[0][q + Q * k];
+    m *= 1.f / (float)nvalid;
+    f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps)
+      if (r0 + ps * RPP < BM && m0 + r0 + ps * RPP < p.M) s2 += (val[ps] - m) * (val[ps] - m);
+    red[1][tid] = s2;
+    __syncthreads();
+    if (tid < Q && n4 < p.ldy) {
+      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < RPP; ++k) c += red[1][tid + Q * k];
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = m;  // r0 == 0: q == tid
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = c;
+    }
+  }
+  (void)cnt;
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+// (TN, KW) for a problem: 64-wide tiles unless N <= 32; split K over the 4 waves when the 128-row tiling leaves the
+// chip under-filled and there is K to split
+static void pw_pick(int M, int ldy, int Ks, int* tn, int* kw) {
+  *tn = ldy <= 32 ? 2 : 4;
+  const int bn = 16 * *tn;
+  const long long wgs = (long long)cdiv(M, 128) * cdiv(ldy, bn);
+  *kw = (wgs < 512 && Ks >= 64) ? 4 : 1;
+  if (const char* f = getenv("VMTL_PW_KW")) {  // tuning aid
+    const int v = atoi(f);
+    if (v == 1 || v == 4) *kw = v;
+  }
+}
+
+extern "C" int vmtl_conv1x1_stats_block(int M, int ldy, int Ks) {
+  int tn, kw;
+  pw_pick(M, ldy, Ks, &tn, &kw);
+  return (4 / kw) * 32;
+}
+
+extern "C" int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks) { return cdiv(M, vmtl_conv1x1_stats_block(M, ldy, Ks)); }
+
+template <int TN, int KW>
+static int launch_pw(PwP& p, hipStream_t st) {
+  p.tiles_m = cdiv(p.M, (4 / KW) * 32);
+  p.tiles_n = cdiv(p.ldy, 16 * TN);
+  hipLaunchKernelGGL((pw_gemm_kernel<TN, KW>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  return vmtl_check_launch();
+}
+
+extern "C" int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int M, int Ks,
+                                int ldy, int Nw, int Cout, void* stream) {
+  VMTL_ENTER();
+  if (!x || !wp || !y || M <= 0 || Ks <= 0 || (Ks & 3) || ldy <= 0 || (ldy & 3)) return VMTL_ERR_ARG;
+  if (Nw <= 0 || Nw > ldy || Cout <= 0 || Cout > Nw) return VMTL_ERR_ARG;
+  PwP p;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = Ks; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
+  int tn, kw;
+  pw_pick(M, ldy, Ks, &tn, &kw);
+  hipStream_t st = (hipStream_t)stream;
+  if (tn == 2) return kw == 4 ? launch_pw<2, 4>(p, st) : launch_pw<2, 1>(p, st);
+  return kw == 4 ? launch_pw<4, 4>(p, st) : launch_pw<4, 1>(p, st);
+}

@@ -355,9 +355,29 @@ def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
     return out
 
 
+_PW = os.environ.get("VMTL_PW", "1") != "0"  # pointwise GEMM kernel for 1x1 convs (csrc/conv_pw.hip)
+_PW_MAX_ROWS = int(os.environ.get("VMTL_PW_MAX_ROWS", str(1 << 19)))
+
+
+def _is_pw(B, Ho, Wo, KH, KW, stride, pad, shuffle=0):
+    return _PW and KH == 1 and KW == 1 and stride == 1 and pad == 0 and not shuffle and B * Ho * Wo <= _PW_MAX_ROWS
+
+
+def conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad):
+    """(rows, pixels per row) of the BatchNorm partial rows a conv launch of this shape emits from its epilogue."""
+    if _is_pw(B, Ho, Wo, KH, KW, stride, pad):
+        M = B * Ho * Wo
+        return lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs), lib().raw("vmtl_conv1x1_stats_block")(M, ldy, Cs)
+    return lib().raw("vmtl_conv2d_stats_rows")(B, Ho, Wo, ldy), lib().raw("vmtl_conv2d_stats_block")(B, Ho, Wo, ldy)
+
+
 def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, shuffle=0, cin=None,
                  algo_flop=None):
     flop = 2.0 * B * Ho * Wo * Nw * KH * KW * (Cs if cin is None else cin)
+    if _is_pw(B, Ho, Wo, KH, KW, stride, pad, shuffle):
+        _k("vmtl_conv1x1_fwd", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y,
+           stats=stats, M=B * Ho * Wo, Ks=Cs, ldy=ldy, Nw=Nw, Cout=Cout)
+        return
     if bias is None and stats is None and not shuffle:
         # plain contraction (data gradients): split K when the tile grid alone cannot fill the chip
         ks = lib().raw("vmtl_conv2d_ksplit")(B, Ho, Wo, ldy, KH * KW * Cs)
@@ -390,7 +410,7 @@ class _Conv2d(torch.autograd.Function):
         y = _empty((B, Ho, Wo, ldy), x)
         stats = None
         if want_stats:
-            rows = lib().raw("vmtl_conv2d_stats_rows")(B, Ho, Wo, ldy)
+            rows, _ = conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad)
             stats = _empty((rows, 2, ldy), x)
         _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Cout, Cout, KH, KW, stride, pad, cin=Cin)
         ctx.save_for_backward(x, weight)
@@ -709,6 +729,9 @@ def up2_conv(xl, C0, skip, weight, want_stats=False):
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False):
     y, stats = _Conv2d.apply(x, weight, bias, stride, pad, want_stats)
+    if stats is not None:  # pixels per statistics row, for whoever finalizes them (bn_act)
+        stats._vmtl_rpb = conv_stats_geometry(y.shape[0], y.shape[1], y.shape[2], x.shape[3], y.shape[3], weight.shape[2],
+                                              weight.shape[3], stride, pad)[1]
     return (y, stats) if want_stats else y
 
 
@@ -827,7 +850,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, mul, res, stats, C, training, momentum, eps,
-                act):
+                act, stats_rpb=0):
         x = _req(x, "x")
         B, H, W, Cs = x.shape
         M = B * H * W
@@ -843,7 +866,7 @@ class _BNAct(torch.autograd.Function):
             if training:
                 if stats is not None:
                     partial, nblk = stats, stats.shape[0]
-                    rpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, Cs)
+                    rpb = stats_rpb if stats_rpb else lib().raw("vmtl_conv2d_stats_block")(B, H, W, Cs)
                     if nblk <= _BN_FUSE_ROWS:
                         # few statistics rows: every thread merges them itself, no separate finalize launch
                         _k("vmtl_bn_apply_fused", x=x, partial=partial, nblk=nblk, rows_per_blk=rpb, eps=eps,
@@ -891,18 +914,22 @@ class _BNAct(torch.autograd.Function):
         dgamma = sum_dzx if (need_sums and ctx.slots[0] is None) else None
         dbeta = sum_dz if (need_sums and ctx.slots[1] is None) else None
         return (dx, dgamma, dbeta, None, None, None, dmul, dy if has_res else None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, nbt, C, training, momentum=0.1, eps=1e-5, act=ACT_NONE,
-           mul=None, res=None, stats=None):
+           mul=None, res=None, stats=None, stats_rpb=0):
+    """stats: BatchNorm partial rows from the producing conv's epilogue, stats_rpb pixels each (0: taken from the
+    `_vmtl_rpb` tag ops.conv2d puts on them, else the implicit-GEMM kernel's row block for this shape)."""
+    if stats is not None and not stats_rpb:
+        stats_rpb = getattr(stats, "_vmtl_rpb", 0)
     return _BNAct.apply(x, gamma, beta, running_mean, running_var, nbt, mul, res, stats, C, training, momentum, eps,
-                        act)
+                        act, stats_rpb)
 
 
 def activation(x, act, C, mul=None):
     """Plain activation (optionally times a gate operand) through the same fused kernel."""
-    return _BNAct.apply(x, None, None, None, None, None, mul, None, None, C, False, 0.0, 0.0, act)
+    return _BNAct.apply(x, None, None, None, None, None, mul, None, None, C, False, 0.0, 0.0, act, 0)
 
 
 # ----------------------------------------------------------------------------- concat / upsample / pad
