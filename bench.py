@@ -90,8 +90,12 @@ def time_conv_kernels(module, batch, reps=3):
         if os.environ.get("VMTL_CONV_TABLE"):
             if "Ho" in kw:
                 M, K, tag = kw["B"] * kw["Ho"] * kw["Wo"], kw["KH"] * kw["KW"] * kw["Cs"], f"k{kw['KH']}s{kw['stride']}"
+            elif "Ks" in kw:
+                M, K, tag = kw["M"], kw["Ks"], "k1s1"
+            elif "H2" in kw:
+                M, K, tag = 4 * kw["B"] * kw["H2"] * kw["W2"], 4 * kw["C0s"] + 9 * kw["C1s"], "up2 "
             else:
-                M, K, tag = kw["B"] * kw["H"] * kw["W"], 9 * kw.get("Cs", 0), "k3s1" if "ep_mode" in kw else "up2 "
+                M, K, tag = kw["B"] * kw["H"] * kw["W"], 9 * kw.get("Cs", 0), "k3s1"
             log(f"{name[5:]:14s} M={M:8d} N={kw.get('Nw', kw.get('Cout', 0)):5d} K={K:6d} {tag} {ms * 1e3:9.1f} us "
                 f"{flop / ms / 1e9:7.1f} TF (executed {xflop / ms / 1e9:6.1f})")
     return fam

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
                                                            const float* __restrict__ dy, int H, int W, int Cs,
                                                            int Ho, int Wo, int K, int stride, int pad, int M, int QL,
                                                            float* partial) {
-  __shared__ f32x4 red[4][16];
+  __shared__ f32x4 red[4][KK][16];  // [wave][tap][quad lane]: ONE barrier for all taps (it was two per tap)
   const int CQ = Cs >> 2;
   const int ql = threadIdx.x & (QL - 1);  // quad lane
   const int rl = threadIdx.x / QL;        // row lane 0 .. 256/QL-1
@@ -111,12 +111,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
     }
-    __syncthreads();
-    if ((int)(threadIdx.x & 63) < QL) red[wave][ql] = v;
-    __syncthreads();
-    if ((int)threadIdx.x < QL && q < CQ) {
-      const f32x4 s = ((red[0][ql] + red[1][ql]) + red[2][ql]) + red[3][ql];
-      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * KK + t) * Cs + (size_t)q * 4) = s;
+    if ((int)(threadIdx.x & 63) < QL) red[wave][t][ql] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < KK * QL; idx += 256) {
+    const int t = idx / QL, l = idx - t * QL;
+    const int qq = blockIdx.x * QL + l;
+    if (qq < CQ) {
+      const f32x4 s = ((red[0][t][l] + red[1][t][l]) + red[2][t][l]) + red[3][t][l];
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * KK + t) * Cs + (size_t)qq * 4) = s;
     }
   }
 }
