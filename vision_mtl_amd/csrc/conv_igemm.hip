@@ -1228,16 +1228,19 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   if (M <= 0 || Nw <= 0 || Ktot <= 0) return 0;
   const long long tiles = (long long)cdiv(Ktot, WG_BNK) * cdiv(Nw, wgrad_rows(Nw));
   long long splits = cdivll(1536, tiles);
-  // pixels per slice at least 16 K-steps (512) - except for SMALL problems (<= 16384 pixels: the deep encoder
-  // layers, whose tile grid is a few dozen workgroups): there 4 K-steps per slice, parallelism over the chip beats
-  // the longer slab sum (measured: the 1x1 weight gradients at M = 1024 / 4096 ran 45-60 us on 28-72 workgroups)
-  static int min_steps_small = -1;
-  if (min_steps_small < 0) {
-    const char* e = getenv("VMTL_WG_MIN_STEPS");  // tuning aid
-    min_steps_small = e ? atoi(e) : 4;
-    if (min_steps_small < 1) min_steps_small = 1;
+  // Pixels per slice: at least 16 K-steps (512) - except for SMALL problems (<= 16384 pixels: the deep encoder layers,
+  // whose tile grid is a few dozen workgroups): there 4 K-steps per slice, parallelism over the chip beats the longer
+  // slab sum (the 1x1 weight gradients at M = 1024 / 4096 ran 45-60 us on 28-72 workgroups; basic bs32 14.4 -> 14.0
+  // ms/step).  Extending the rule to 65536 / all sizes measured +0.05..0.1 ms (VMTL_WG_SMALL_M).
+  static int min_steps = -1, small_m = -1;
+  if (min_steps < 0) {
+    const char* e = getenv("VMTL_WG_MIN_STEPS");  // tuning aids
+    min_steps = e ? atoi(e) : 4;
+    if (min_steps < 1) min_steps = 1;
+    const char* e2 = getenv("VMTL_WG_SMALL_M");
+    small_m = e2 ? atoi(e2) : 16384;
   }
-  const long long max_by_rows = cdiv(M, (M <= 16384 ? min_steps_small : 16) * BP);
+  const long long max_by_rows = cdiv(M, (M <= small_m ? min_steps : 16) * BP);
   const long long max_by_mem = (32ll << 20) / ((long long)Nw * Ktot);  // slabs <= 128 MB
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits > max_by_mem) splits = max_by_mem;
