@@ -6,10 +6,13 @@ all-reduce when N > 1]) on synthetic data, fp32, model in train mode — BASELIN
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0.  Besides the driver contract it carries
-  roofline     : the implicit-GEMM conv kernel (conv_igemm_kernel, forward + data-gradient launches
-                 of one step) timed launch-by-launch with HIP events on the launch stream;
-                 achieved = algorithmic FLOPs per launch / average launch duration, peak = 157.3 TF
-                 (exact-fp32 MFMA, MI355X_MICROARCH.md)
+  roofline     : the forward + data-gradient conv launches of one step (conv_igemm_kernel and its two
+                 specialisations conv3x3_small_kernel / pw_gemm_kernel) timed launch-by-launch with HIP
+                 events on the launch stream; achieved = algorithmic FLOPs per launch / average launch
+                 duration, peak = 157.3 TF (exact-fp32 MFMA, MI355X_MICROARCH.md)
+  configs      : (default 1-GPU invocation only) the same measurement for the other BASELINE.json
+                 configurations: basic bs=8, basic 256x256, csnet (+ the cross-stitch kernel's HBM
+                 roofline), mtan 256x256 bs=16 (+ algorithmic HBM GB/s)
   cpu_baseline : the oracle (CPU restatement of the same step graph, oracle/) timed on the host
                  cores of this box on a bounded sample; a reported baseline, not the target.
 """
@@ -72,7 +75,8 @@ def time_conv_kernels(module, batch, reps=3):
         rec, ops._RECORD = ops._RECORD, None
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
-    fam = {"vmtl_conv2d_fwd": dict(flop=0.0, ms=0.0, launches=0), "vmtl_conv2d_wgrad": dict(flop=0.0, ms=0.0, launches=0)}
+    fam = {"vmtl_conv2d_fwd": dict(flop=0.0, ms=0.0, launches=0), "vmtl_conv2d_wgrad": dict(flop=0.0, ms=0.0, launches=0),
+           "vmtl_stitch": dict(flop=0.0, ms=0.0, launches=0, bytes=0.0)}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, kw, flop, xflop in rec:  # flop = algorithmic (reference-formulation) FLOPs, xflop = executed
         lib().callk(name, stream=stream, **kw)  # warm
@@ -81,13 +85,15 @@ def time_conv_kernels(module, batch, reps=3):
             lib().callk(name, stream=stream, **kw)
         e1.record()
         e1.synchronize()
-        f = fam["vmtl_conv2d_wgrad" if name == "vmtl_conv2d_wgrad" else "vmtl_conv2d_fwd"]
+        f = fam[name if name in ("vmtl_conv2d_wgrad", "vmtl_stitch") else "vmtl_conv2d_fwd"]
         ms = e0.elapsed_time(e1) / reps
+        if name == "vmtl_stitch":  # HBM-bound: flop slot carries algorithmic bytes (8 B per element)
+            f["bytes"] += flop
         f["flop"] += flop
         f["xflop"] = f.get("xflop", 0.0) + xflop
         f["ms"] += ms
         f["launches"] += 1
-        if os.environ.get("VMTL_CONV_TABLE"):
+        if os.environ.get("VMTL_CONV_TABLE") and name != "vmtl_stitch":
             if "Ho" in kw:
                 M, K, tag = kw["B"] * kw["Ho"] * kw["Wo"], kw["KH"] * kw["KW"] * kw["Cs"], f"k{kw['KH']}s{kw['stride']}"
             elif "Ks" in kw:
@@ -152,36 +158,17 @@ def cpu_baseline(args):
             "sample": f"oracle {args.model} {args.height}x{args.width} bs={bs} fwd+CE+SILog+bwd, {n} steps in {dt:.1f}s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="basic", choices=["basic", "mtan", "csnet"])
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
-    ap.add_argument("--height", type=int, default=128)
-    ap.add_argument("--width", type=int, default=256)
-    ap.add_argument("--classes", type=int, default=19)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--adam", action="store_true", help="include the fused Adam update in the timed step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+def measure(args, device, rank, world, extras=False):
+    """One configuration: build, warm up, capture, time exactly args.steps steps; returns the result object
+    (rank 0; None elsewhere).  extras: add the roofline (per-launch conv timing) and, at N = 1, the CPU baseline."""
+    import torch.distributed as dist
 
     from vision_mtl_amd import dp, ops
 
-    rank, world, local_rank = dp.init_distributed()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
-    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(device)}; building {args.model}")
     model, module = build(args, device)
     arena = dp.FlatArena(model)
     batch = make_batch(args, device, rank)
-    log("model + batch resident")
-    import torch.distributed as dist
+    log(f"{args.model} {args.height}x{args.width} bs={args.batch}: model + batch resident")
 
     def step():
         ops.stamp("step start")
@@ -254,58 +241,135 @@ def main():
             log(f"stamp {(v - t0) / 100.0:10.1f} us  {tag}")
     loss_val = float((static_loss if graph is not None else step()).item())
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
+    if rank != 0:
+        return None
 
+    ms = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+    out = {
+        "metric": f"images/sec fwd+bwd, {args.model} model {args.height}x{args.width}",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.height}x{args.width} C={args.classes} bs={args.batch}/GPU, "
+                               f"train-mode fwd + CE + SILog + bwd" + (" + Adam" if args.adam else "")
+                               + (" + 1 RCCL grad all-reduce" if world > 1 else ""),
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "launch": "eager" if graph is None else "hipGraph replay", "loss": round(loss_val, 5)},
+    }
+    gf = STEP_GFLOP_PER_IMG.get((args.model, args.height, args.width))
+    if gf:
+        tf = gf * value / world / 1e3
+        out["config"]["step_tflops_per_gpu"] = round(tf, 2)
+        out["config"]["step_frac_of_fp32_mfma_peak"] = round(tf / PEAK_TFLOPS_FP32_MFMA, 4)
+    if args.model == "mtan" and (args.height, args.width) == (256, 256):
+        # ~3.2 GB of minimum activation traffic per image and step (conv outputs written once +
+        # read once forward, ~3x that backward); quoted next to the MFMA figure because MTAN sits near the ridge
+        gbps = 3.2 * value / world
+        out["config"]["algorithmic_hbm_GBps"] = round(gbps, 1)
+        out["config"]["algorithmic_hbm_frac_of_8TBps"] = round(gbps / 8000.0, 4)
+    if not args.no_roofline:
+        fam = time_conv_kernels(module, batch)
+        log("per-launch conv timing done")
+        ig = fam["vmtl_conv2d_fwd"]
+        ach = ig["flop"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
+                           "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": None,
+                           "kernel": "forward + data-gradient conv launches of one step (conv_igemm_kernel, "
+                                     "conv3x3_small_kernel, pw_gemm_kernel)",
+                           "launches_per_step": ig["launches"],
+                           "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
+                           "flop_per_launch": round(ig["flop"] / max(ig["launches"], 1)),
+                           "executed_tflops": round(ig.get("xflop", ig["flop"]) / (ig["ms"] * 1e-3) / 1e12, 2),
+                           "ms_per_step_in_kernel": round(ig["ms"], 3)}
+        # HBM bytes per launch from the hardware counters: cannot be collected inside this process, so the
+        # committed rocprofv3 --pmc summary of this same workload is quoted (profiles/, tools/profile_configs.sh)
+        tag = {("basic", 128, 256, 32): "basic", ("basic", 128, 256, 8): "basic_bs8", ("basic", 256, 256, 32): "basic_256",
+               ("csnet", 128, 256, 32): "csnet", ("mtan", 256, 256, 16): "mtan"}.get((args.model, args.height, args.width, args.batch))
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_{tag}_pmc.json")
+        if tag and os.path.exists(pmc):
+            with open(pmc) as f:
+                ks = json.load(f)["kernels"]
+            fams = [ks[k] for k in ("conv_igemm_kernel", "conv3x3_small_kernel", "pw_gemm_kernel") if k in ks and "hbm_bytes_per_launch" in ks[k]]
+            if fams:
+                tot = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in fams)
+                out["roofline"]["traffic"] = round(tot / sum(k["launches"] for k in fams))
+                out["roofline"]["traffic_unit"] = ("HBM bytes per launch over the same kernels (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                                   f"WRITE_SIZE, profiles/r02_{tag}_pmc.json)")
+        wg = fam["vmtl_conv2d_wgrad"]
+        if wg["ms"] > 0:
+            wach = wg["flop"] / (wg["ms"] * 1e-3) / 1e12
+            out["roofline"]["wgrad_kernel"] = {"achieved": round(wach, 2), "frac": round(wach / PEAK_TFLOPS_FP32_MFMA, 4),
+                                               "launches_per_step": wg["launches"],
+                                               "ms_per_step_in_kernel": round(wg["ms"], 3)}
+        st = fam.get("vmtl_stitch")
+        if st and st["ms"] > 0:
+            # the cross-stitch kernel is HBM-bound: 8 B per element (read + write), SURVEY.md section 8(d)
+            gb = st["bytes"] / (st["ms"] * 1e-3) / 1e9
+            out["roofline"]["stitch_kernel"] = {"bound": "hbm", "achieved": round(gb, 1), "peak": 8000.0, "unit": "GB/s",
+                                                "frac": round(gb / 8000.0, 4), "launches_per_step": st["launches"],
+                                                "bytes_per_launch": round(st["bytes"] / st["launches"]),
+                                                "ms_per_step_in_kernel": round(st["ms"], 3)}
+    if world == 1 and extras and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    # drop this configuration's device state before the next one is built
+    del graph, arena, module, model, batch
+    ops.packs.refresh()
+    torch.cuda.empty_cache()
+    return out
+
+
+# the other BASELINE.json configurations, timed after the headline by the default 1-GPU invocation
+EXTRA_CONFIGS = [dict(model="basic", batch=8, height=128, width=256, classes=19),    # the metric string's literal bs=8
+                 dict(model="basic", batch=32, height=256, width=256, classes=19),   # north_star: "and 256x256 batches"
+                 dict(model="csnet", batch=32, height=128, width=256, classes=19),   # configs[2]
+                 dict(model="mtan", batch=16, height=256, width=256, classes=14)]    # configs[3]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="basic", choices=["basic", "mtan", "csnet"])
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--classes", type=int, default=19)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--adam", action="store_true", help="include the fused Adam update in the timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--only-headline", action="store_true", help="skip the `configs` array of the other BASELINE configurations")
+    args = ap.parse_args()
+
+    from vision_mtl_amd import dp
+
+    rank, world, local_rank = dp.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    log(f"rank {rank}/{world} on {torch.cuda.get_device_name(device)}; building {args.model}")
+    out = measure(args, device, rank, world, extras=True)
+    default_headline = (args.model, args.batch, args.height, args.width) == ("basic", 32, 128, 256)
+    if rank == 0 and world == 1 and default_headline and not args.only_headline and not args.no_graph:
+        # driver-visible lines for the other BASELINE.json configurations (same measurement, fewer steps)
+        out["configs"] = []
+        for c in EXTRA_CONFIGS:
+            a = argparse.Namespace(**{**vars(args), **c, "steps": min(args.steps, 10), "warmup": min(args.warmup, 3)})
+            r = measure(a, device, rank, world)
+            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in r}
+            keep["config"] = r["config"]
+            if "roofline" in r:
+                keep["roofline"] = r["roofline"]
+            out["configs"].append(keep)
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        value = args.batch * world * args.steps / dt
-        out = {
-            "metric": f"images/sec fwd+bwd, {args.model} model {args.height}x{args.width}",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.height}x{args.width} C={args.classes} bs={args.batch}/GPU, "
-                                   f"train-mode fwd + CE + SILog + bwd" + (" + Adam" if args.adam else "")
-                                   + (" + 1 RCCL grad all-reduce" if world > 1 else ""),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": "eager" if graph is None else "hipGraph replay", "loss": round(loss_val, 5)},
-        }
-        gf = STEP_GFLOP_PER_IMG.get((args.model, args.height, args.width))
-        if gf:
-            tf = gf * value / world / 1e3
-            out["config"]["step_tflops_per_gpu"] = round(tf, 2)
-            out["config"]["step_frac_of_fp32_mfma_peak"] = round(tf / PEAK_TFLOPS_FP32_MFMA, 4)
-        if not args.no_roofline:
-            fam = time_conv_kernels(module, batch)
-            log("per-launch conv timing done")
-            ig = fam["vmtl_conv2d_fwd"]
-            ach = ig["flop"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_FP32_MFMA,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_FP32_MFMA, 4), "traffic": None,
-                               "kernel": "conv_igemm_kernel (forward + data-gradient launches of one step)",
-                               "launches_per_step": ig["launches"],
-                               "avg_launch_us": round(ig["ms"] * 1e3 / max(ig["launches"], 1), 2),
-                               "flop_per_launch": round(ig["flop"] / max(ig["launches"], 1)),
-                               "executed_tflops": round(ig.get("xflop", ig["flop"]) / (ig["ms"] * 1e-3) / 1e12, 2),
-                               "ms_per_step_in_kernel": round(ig["ms"], 3)}
-            # HBM bytes per launch from the hardware counters: cannot be collected inside this process, so the
-            # committed rocprofv3 --pmc summary of this same workload is quoted (profiles/)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_hbm_traffic_pmc.json")
-            if (args.model, args.height, args.width, args.batch) == ("basic", 128, 256, 32) and os.path.exists(pmc):
-                with open(pmc) as f:
-                    k = json.load(f)["kernels"].get("conv_igemm_kernel")
-                if k:
-                    out["roofline"]["traffic"] = round(k["hbm_bytes_per_launch"])
-                    out["roofline"]["traffic_unit"] = "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-            wg = fam["vmtl_conv2d_wgrad"]
-            if wg["ms"] > 0:
-                wach = wg["flop"] / (wg["ms"] * 1e-3) / 1e12
-                out["roofline"]["wgrad_kernel"] = {"achieved": round(wach, 2), "frac": round(wach / PEAK_TFLOPS_FP32_MFMA, 4),
-                                                   "launches_per_step": wg["launches"],
-                                                   "ms_per_step_in_kernel": round(wg["ms"], 3)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
+
         dist.barrier()
         dist.destroy_process_group()
 

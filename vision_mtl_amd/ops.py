@@ -1180,7 +1180,8 @@ class _Stitch(torch.autograd.Function):
         off = (task * T + task) * (weights.shape[2] if channel_wise else 1)
         wview = weights.view(-1)[off:]
         y = _empty(x.shape, x)
-        _k("vmtl_stitch", x=x, w=wview, y=y, M=B * H * W, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
+        # _flop slot = algorithmic BYTES here (8 B per element: read + write) for bench.py's HBM roofline
+        _k("vmtl_stitch", _flop=8.0 * B * H * W * C, x=x, w=wview, y=y, M=B * H * W, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
         ctx.save_for_backward(x, weights)
         ctx.cfg = (task, C, channel_wise, off)
         ctx.slot = _slot(weights)
