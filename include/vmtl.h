@@ -223,6 +223,7 @@ int vmtl_channel_scale_add(const float* x, const float* s, const float* t, float
 int vmtl_stitch(const float* x, const float* w, float* y, long long M, int C, int Cs, int wstride, void* stream);
 /* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */
 int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream);
+int vmtl_fill_zero(float* p, long long n, void* stream); /* n floats <- 0 (a memset node) */
 /* lit_module.py:137-138 (argmax of softmax == argmax of logits) */
 int vmtl_argmax_channels(const float* z, long long* out, int B, int HW, int C, long long sb, long long sc,
                          long long sp, void* stream);

@@ -23,6 +23,7 @@ args_of() {
 }
 for cfg in $CONFIGS; do
   A=$(args_of $cfg)
+  mkdir -p $OUT/$cfg
   echo "== $cfg: kernel trace" >&2
   VMTL_SIDE_STREAM=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$cfg/trace -- \
     python3 $ROOT/bench.py $A --steps 5 --warmup 2 --no-cpu-baseline --only-headline \
@@ -42,3 +43,5 @@ for cfg in $CONFIGS; do
   python3 $ROOT/tools/pmc_summary.py $OUT/$cfg "$A" > $ROOT/profiles/${ROUND}_${cfg}_pmc.json
   echo "== $cfg done" >&2
 done
+# gpurun only brings gpurun_out/ back: keep a copy of the summaries there
+mkdir -p $ROOT/gpurun_out/profiles_$ROUND && cp $ROOT/profiles/${ROUND}_* $ROOT/gpurun_out/profiles_$ROUND/

@@ -536,3 +536,12 @@ extern "C" int vmtl_hwc_to_nhwc_pad(const float* x, float* y, long long P, int C
   hipLaunchKernelGGL(hwc_pad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, Cs, scale, total);
   return vmtl_check_launch();
 }
+
+// n floats <- 0 (memset node: capturable).  The bias gradient of a conv that feeds a train-mode BatchNorm is
+// analytically zero (the batch mean absorbs the bias: reference models/mtan_model.py:31-47 build exactly that), so
+// those gradients are written as zeros instead of being summed out of dY.
+extern "C" int vmtl_fill_zero(float* p, long long n, void* stream) {
+  VMTL_ENTER();
+  if (!p || n <= 0) return VMTL_ERR_ARG;
+  return hipMemsetAsync(p, 0, (size_t)n * sizeof(float), (hipStream_t)stream) == hipSuccess ? VMTL_OK : VMTL_ERR_LAUNCH;
+}

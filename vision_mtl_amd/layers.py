@@ -62,7 +62,8 @@ def conv_bn_act(x: Act, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | N
     """act(BN(conv(x))) [* mul] [+ res] with the BatchNorm column sums taken from the conv epilogue."""
     train = bn.training
     if c.groups == 1:
-        out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train)
+        out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train,
+                         zero_bias_grad=train and c.bias is not None)
         y, stats = out if train else (out, None)
     else:
         if c.groups != c.in_channels or c.in_channels != c.out_channels or c.bias is not None:

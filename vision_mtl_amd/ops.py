@@ -195,6 +195,7 @@ class _PackCache:
     def __init__(self):
         self.entries = {}  # key -> dict(dst, params, wref, ptr, version, epoch)
         self.custom = {}   # key -> dict(dst, fn, wref, ptr, version, epoch): operands with their own pack kernel
+        self.shared_bufs = {}  # key -> (weakref of the anchoring weight, buffer)
         self.epoch = 0
         self.table = None  # (device uint8 tensor, n, total)
         self.live = []
@@ -214,11 +215,13 @@ class _PackCache:
         n = len(self.entries) + len(self.custom)
         self.entries = {k: e for k, e in self.entries.items() if self._alive(e)}
         self.custom = {k: e for k, e in self.custom.items() if self._alive(e)}
+        self.shared_bufs = {k: e for k, e in self.shared_bufs.items() if e[0]() is not None}
         if len(self.entries) + len(self.custom) != n:
             self.dirty = True
 
-    def get(self, weight, kind, params, offset=0):
-        """params = (R1, R0, T, C, Cs, sr1, sr0, st, sc, flip); offset = first element of the weight to read."""
+    def get(self, weight, kind, params, offset=0, out=None):
+        """params = (R1, R0, T, C, Cs, sr1, sr0, st, sc, flip); offset = first element of the weight to read;
+        out: destination for a NEW entry (a slice of a caller-owned persistent buffer, see shared())."""
         key = (id(weight), kind, params, offset)
         e = self.entries.get(key)
         if e is not None and e["wref"]() is not weight:  # id() of a dead tensor reused by a new one
@@ -226,14 +229,24 @@ class _PackCache:
         if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
             return e["dst"]
         R1, R0, T, C, Cs = params[:5]
-        if e is None or e["ptr"] != weight.data_ptr():
-            e = {"dst": _empty((R1 * R0, T * Cs), weight), "params": params, "wref": weakref.ref(weight),
-                 "ptr": weight.data_ptr(), "offset": offset}
+        if e is None or e["ptr"] != weight.data_ptr() or (out is not None and e["dst"].data_ptr() != out.data_ptr()):
+            e = {"dst": _empty((R1 * R0, T * Cs), weight) if out is None else out, "params": params,
+                 "wref": weakref.ref(weight), "ptr": weight.data_ptr(), "offset": offset}
             self.entries[key] = e
             self.dirty = True
         pack(weight.view(-1)[offset:] if offset else weight, *params, out=e["dst"])
         e["version"], e["epoch"] = weight._version, self.epoch
         return e["dst"]
+
+    def shared(self, anchor, kind, shape):
+        """A persistent buffer several entries pack into (e.g. the two heads' weights as ONE GEMM operand); it lives as
+        long as `anchor` (a weight) does."""
+        key = (id(anchor), kind, tuple(shape))
+        e = self.shared_bufs.get(key)
+        if e is None or e[0]() is not anchor:
+            e = (weakref.ref(anchor), _empty(shape, anchor))
+            self.shared_bufs[key] = e
+        return e[1]
 
     def get_custom(self, weight, kind, shape, fn):
         """Operand built by its own kernel (fn(weight, dst) launches it): cached like get(); refresh() rebuilds
@@ -395,7 +408,7 @@ class _Conv2d(torch.autograd.Function):
     """y = conv2d(x, weight) (+ bias); weight stays in torch (Cout, Cin, KH, KW) layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, want_stats):
+    def forward(ctx, x, weight, bias, stride, pad, want_stats, zero_bias_grad=False):
         x = _req(x, "x")
         weight = _req(weight, "weight")
         B, H, W, Cs = x.shape
@@ -415,6 +428,7 @@ class _Conv2d(torch.autograd.Function):
         _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Cout, Cout, KH, KW, stride, pad, cin=Cin)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None)
+        ctx.zero_bias_grad = bool(zero_bias_grad)
         ctx.slots = (_slot(weight), _slot(bias))
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" tensor for the stats output
         if want_stats:
@@ -427,7 +441,7 @@ class _Conv2d(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dy = _req(dy, "dy")
         B, H, W, Cs = x.shape
         Cout, Cin, KH, KW = weight.shape
@@ -452,10 +466,15 @@ class _Conv2d(torch.autograd.Function):
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
             with side.branch(ctx.slots[1] is not None, B * Ho * Wo, fork, dy):
-                db = _colsum(dy, None, B * Ho * Wo, Cout, ldy, out=ctx.slots[1])
+                if ctx.zero_bias_grad:
+                    # the conv feeds a train-mode BatchNorm: the batch mean absorbs the bias, its gradient is exactly 0
+                    db = _empty((Cout,), x) if ctx.slots[1] is None else ctx.slots[1]
+                    _k("vmtl_fill_zero", p=db, n=Cout)
+                else:
+                    db = _colsum(dy, None, B * Ho * Wo, Cout, ldy, out=ctx.slots[1])
             if ctx.slots[1] is not None:
                 db = None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _Up2Conv(torch.autograd.Function):
@@ -727,8 +746,9 @@ def up2_conv(xl, C0, skip, weight, want_stats=False):
     return _Up2Conv.apply(xl, skip, weight, C0, want_stats)
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False):
-    y, stats = _Conv2d.apply(x, weight, bias, stride, pad, want_stats)
+def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False, zero_bias_grad=False):
+    """zero_bias_grad: the caller normalises y with a TRAIN-mode BatchNorm next, which makes dL/dbias exactly zero."""
+    y, stats = _Conv2d.apply(x, weight, bias, stride, pad, want_stats, zero_bias_grad)
     if stats is not None:  # pixels per statistics row, for whoever finalizes them (bn_act)
         stats._vmtl_rpb = conv_stats_geometry(y.shape[0], y.shape[1], y.shape[2], x.shape[3], y.shape[3], weight.shape[2],
                                               weight.shape[3], stride, pad)[1]
@@ -1350,12 +1370,13 @@ class _DecoderTail(torch.autograd.Function):
         _small(x1, wp2, x2, B, H, W, Cs1, ldy2, C2, C2, 2.0 * M * C2 * 9 * C1, pa=pa1, pc=pc1, act_in=ACT_RELU, a_out=a1,
                stats=stats2, ep_mode=1 if tr2 else 0)
         mean2, invstd2, pa2, pc2 = _bn_fwd_coef(x2, stats2, rpb, g2, b2, rm2, rv2, nbt2, C2, tr2, mom2, eps2)
-        wph = _empty((N, 9 * ldy2), x1)
-        pack(wa, 1, Ca, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=wph[:Ca])
-        pack(wb, 1, Cb, 9, C2, ldy2, 0, C2 * 9, 1, 9, out=wph[Ca:])
-        bias = _empty((N,), x1)
-        _copy_vec(ba, bias, Ca)
-        _copy_vec(bb, bias[Ca:], Cb)
+        # both heads as ONE GEMM operand / bias vector, kept packed by the step's batched packing launch
+        wph = packs.shared(wa, "heads_fwd", (N, 9 * ldy2))
+        packs.get(wa, "heads_fwd", (1, Ca, 9, C2, ldy2, 0, C2 * 9, 1, 9, 0), out=wph[:Ca])
+        packs.get(wb, "heads_fwd", (1, Cb, 9, C2, ldy2, 0, C2 * 9, 1, 9, 0), out=wph[Ca:])
+        bias = packs.shared(wa, "heads_bias", (N,))
+        packs.get(ba, "heads_bias", (1, 1, 1, Ca, Ca, 0, 0, 0, 1, 0), out=bias[:Ca])
+        packs.get(bb, "heads_bias", (1, 1, 1, Cb, Cb, 0, 0, 0, 1, 0), out=bias[Ca:])
         a2 = _empty(x2.shape, x1) if need_bwd else None
         oa, ob = _empty((B, Ca, H, W), x1), _empty((B, Cb, H, W), x1)
         _small(x2, wph, oa, B, H, W, ldy2, ldyh, N, N, 2.0 * M * N * 9 * C2, pa=pa2, pc=pc2, act_in=ACT_RELU, a_out=a2,
