@@ -41,6 +41,7 @@ for cfg in $CONFIGS; do
       > $OUT/$cfg/pmc$i.json 2> $OUT/$cfg/pmc$i.err
   done
   python3 $ROOT/tools/pmc_summary.py $OUT/$cfg "$A" > $ROOT/profiles/${ROUND}_${cfg}_pmc.json
+  rm -rf $OUT/$cfg/trace $OUT/$cfg/pmc[0-9]  # raw per-dispatch CSVs: tens of MB per config (gpurun returns <= 64 MiB)
   echo "== $cfg done" >&2
 done
 # gpurun only brings gpurun_out/ back: keep a copy of the summaries there

@@ -124,14 +124,30 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   }
 }
 
-// dw[c][tap] (torch layout (C,1,K,K)) = sum over partial rows, fp64
+// dw[c][tap] (torch layout (C,1,K,K)) = sum over partial rows, fp64, fixed order.  A workgroup owns 32 consecutive
+// (tap, channel) elements x 8 row groups: consecutive threads read consecutive channels of a partial row, each sums
+// every 8th row, LDS folds the 8 groups.  (One workgroup per element launched C*K*K = 24,000 workgroups of two
+// barriers for the 960-channel 5x5 layers; one thread per element left a 256-load serial chain: 32 us.)
 __global__ __launch_bounds__(256) void dwconv_bwd_w_finalize_kernel(const float* __restrict__ partial, int nblk,
                                                                     int KK, int C, int Cs, float* dw) {
-  __shared__ double sh[4];
-  const int i = blockIdx.x;  // one workgroup per (channel, tap)
-  const int c = i / KK, t = i - c * KK;
-  const double s = block_rows_sum(partial, nblk, KK, t, Cs, c, sh);
-  if (threadIdx.x == 0) dw[i] = (float)s;
+  __shared__ double sh[8][32];
+  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
+  double s = 0.0;
+  int t = 0, c = 0;
+  if (i < KK * C) {
+    t = i / C;
+    c = i - t * C;
+    for (int b = rg; b < nblk; b += 8) s += (double)partial[((size_t)b * KK + t) * Cs + c];
+  }
+  sh[rg][e] = s;
+  __syncthreads();
+  if (rg == 0 && i < KK * C) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += sh[k][e];
+    dw[c * KK + t] = (float)tot;
+  }
 }
 
 static inline int dw_grid(long long total4) {
@@ -194,7 +210,7 @@ extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* pa
   else
     hipLaunchKernelGGL((dwconv_bwd_w_kernel<25>), dim3(panels, nblk), dim3(256), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
                        stride, pad, M, QL, partial);
-  hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(C * K * K), dim3(256), 0, st, partial, nblk, K * K, C, Cs,
-                     dw);
+  hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(cdiv(C * K * K, 32)), dim3(256), 0, st, partial, nblk, K * K,
+                     C, Cs, dw);
   return vmtl_check_launch();
 }

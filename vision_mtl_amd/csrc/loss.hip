@@ -87,6 +87,40 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const float* __restr
   }
 }
 
+// vmtl_ce_bwd_strided with a channel-contiguous gradient (NHWC rows of ld >= ceil4(C) floats): one thread per
+// (pixel, channel quad), so a wave writes 1 KB of CONTIGUOUS gradient (one thread per pixel left every store
+// instruction touching 64 lanes x 16 bytes at an 80-byte stride: 2-4x slower than the NCHW form).  The softmax
+// statistics of a pixel are recomputed by its Q = ceil(C/4) threads (reads hit L1; ~2*C expf each).
+__global__ __launch_bounds__(CE_THREADS) void ce_bwd_nhwc_kernel(const float* __restrict__ z,
+                                                                 const long long* __restrict__ tgt,
+                                                                 const float* __restrict__ gout, float* __restrict__ dz,
+                                                                 long long P, int HW, int C, long long sb, long long sc,
+                                                                 long long sp, int ld) {
+  const float g = gout[0] / (float)P;
+  const int Q = (C + 3) >> 2;
+  const long long total = P * Q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long i = idx / Q;
+    const int q = (int)(idx - i * Q);
+    const long long b = i / HW, hw = i - b * HW;
+    const long long off = b * sb + hw * sp;
+    float m = z[off];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, z[off + c * sc]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(z[off + c * sc] - m);
+    const float inv = 1.f / s;
+    const long long t = tgt[i];
+    const float bad = (t < 0 || t >= C) ? __int_as_float(0x7fc00000) : 0.f;  // as the forward: NaN, never a silent 0
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * q + e;
+      v[e] = c < C ? (expf(z[off + c * sc] - m) * inv - (c == t ? 1.f : 0.f)) * g + bad : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dz + i * ld + 4 * q) = v;
+  }
+}
+
 static inline int ce_blocks(long long P) {
   long long nb = cdivll(P, CE_THREADS);
   if (nb > 2048) nb = 2048;
@@ -133,6 +167,13 @@ extern "C" int vmtl_ce_bwd_strided(const float* logits, const long long* target,
   VMTL_ENTER();
   if (!logits || !target || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   const long long P = (long long)B * HW;
+  if (dsc == 1 && (dsp & 3) == 0 && dsp >= ((C + 3) & ~3) && dsb == dsp * HW) {
+    long long nb = cdivll(P * ((C + 3) >> 2), CE_THREADS);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(ce_bwd_nhwc_kernel, dim3((int)nb), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target,
+                       grad_out, dlogits, P, HW, C, sb, sc, sp, (int)dsp);
+    return vmtl_check_launch();
+  }
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(ce_blocks(P)), dim3(CE_THREADS), 0, (hipStream_t)stream, logits, target,
                      grad_out, dlogits, P, HW, C, sb, sc, sp, dsb, dsc, dsp);
   return vmtl_check_launch();

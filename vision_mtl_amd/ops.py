@@ -1289,8 +1289,13 @@ class _ToNCHW(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dy = _req(dy, "dy")
         B, C, H, W = dy.shape
+        ld = ctx.Cs
+        if (dy.is_cuda and dy.dtype == torch.float32 and dy.stride() == (H * W * ld, 1, W * ld, ld) and dy.storage_offset() == 0
+                and dy.untyped_storage().nbytes() == 4 * B * H * W * ld and getattr(dy, "_vmtl_nhwc", None) is not None):
+            # the cross-entropy backward already wrote this gradient as NHWC rows of exactly our width, pad lanes zero
+            return torch.as_strided(dy, (B, H, W, ld), (H * W * ld, W * ld, ld, 1)), None
+        dy = _req(dy, "dy")
         dx = _empty((B, H, W, ctx.Cs), dy)
         _k("vmtl_nchw_to_nhwc", x=dy, y=dx, B=B, C=C, HW=H * W, Cs=ctx.Cs, Cw=ctx.Cs)
         return dx, None
