@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // statistics accumulated over this workgroup's tiles (threads tid < SQ own one channel quad each)
   f32x4 wg_a = {0.f, 0.f, 0.f, 0.f}, wg_c = wg_a;
   float wg_n = 0.f;
+  // acc_rows: every epilogue lane keeps ITS OWN sums over all the tiles it sees (fixed channel quad per lane) and the
+  // lanes are folded ONCE, after the last tile - no per-tile barriers / LDS passes for the statistics.
+  //   mode 2: la = sum dz, lc = sum dz*xhat;   mode 1: shifted sums around the lane's first value lk (accurate when
+  //   |mean| >> std): la = sum (v - lk), lc = sum (v - lk)^2, ln = count.
+  f32x4 la = {0.f, 0.f, 0.f, 0.f}, lc = la, lk = la;
+  float ln = 0.f;
   int t = blockIdx.x;
   int nb = 0, nh0 = 0, nw0 = 0;
   if (t < p.ntiles) {
@@ -434,13 +440,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         } else {
           v += epar[eq];
           if (ok) s1 += v;
+          if (p.ep_mode == 1 && p.acc_rows && ok) {
+            if (ln == 0.f) lk = v;
+            const f32x4 d = v - lk;
+            la += d;
+            lc += d * d;
+            ln += 1.f;
+          }
         }
         val[it] = v;
         if (ok) *reinterpret_cast<f32x4*>(p.y + (unsigned)(pixrow + px) * (unsigned)p.ldy + 4 * eq) = v;
       }
     }
 
-    if (p.ep_mode != 0) {
+    if (p.ep_mode == 2 && p.acc_rows) {
+      la += s1;
+      lc += s2;
+    } else if (p.ep_mode != 0 && !p.acc_rows) {
       // per-tile column sums: lane partials -> LDS -> the first SQ threads add the 4 x PPI partials of their quad
       red[wv * 64 + lane] = s1;
       red[256 + wv * 64 + lane] = s2;
@@ -468,16 +484,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int w = 0; w < 4; ++w)
 #pragma unroll
             for (int q = 0; q < PPI; ++q) c += red[256 + w * 64 + q * SQ + tid];
-          if (p.acc_rows) {  // Chan's merge of (count, mean, M2) with the tiles seen so far
-            constexpr float nt = (float)(CSM_TH * CSM_TW);
-            const f32x4 d = m - wg_a;
-            wg_a += d * (nt / (wg_n + nt));
-            wg_c += c + d * d * (wg_n * nt / (wg_n + nt));
-            wg_n += nt;
-          } else {
-            *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = m;  // tid == eq for these lanes
-            *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
-          }
+          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = m;  // tid == eq for these lanes
+          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
         }
       } else if (tid < SQ && 4 * tid < p.ldy) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
@@ -488,19 +496,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a += red[w * 64 + q * SQ + tid];
             c += red[256 + w * 64 + q * SQ + tid];
           }
-        if (p.acc_rows) {
-          wg_a += a;
-          wg_c += c;
-        } else {
-          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = a;
-          *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
-        }
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 0) * p.ldy + 4 * tid) = a;
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)t * 2 + 1) * p.ldy + 4 * tid) = c;
       }
     }
   }
-  if (p.ep_mode != 0 && p.acc_rows && tid < SQ && 4 * tid < p.ldy) {
-    *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + 4 * tid) = wg_a;
-    *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + 4 * tid) = wg_c;
+  if (p.ep_mode != 0 && p.acc_rows) {
+    // fold the lanes' sums of this workgroup into its statistics row (once per kernel)
+    __syncthreads();  // the last tile's output image / halo is dead
+    f32x4* fold = halo;  // [3][256]
+    if (p.ep_mode == 1) {  // lane (count, mean, M2) from its shifted sums
+      f32x4 mean = lk, m2 = {0.f, 0.f, 0.f, 0.f};
+      if (ln > 0.f) {
+        mean = lk + la * (1.f / ln);
+        m2 = lc - la * la * (1.f / ln);
+      }
+      fold[tid] = mean;
+      fold[256 + tid] = m2;
+      fold[512 + tid] = (f32x4){ln, 0.f, 0.f, 0.f};
+    } else {
+      fold[tid] = la;
+      fold[256 + tid] = lc;
+    }
+    __syncthreads();
+    if (tid < SQ && 4 * tid < p.ldy) {
+      if (p.ep_mode == 1) {  // Chan's merge over the 4 x PPI lanes of this channel quad
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int q = 0; q < PPI; ++q) {
+            const int j = w * 64 + q * SQ + tid;
+            const float nb = fold[512 + j][0];
+            if (nb > 0.f) {
+              const float nt = wg_n + nb;
+              const f32x4 d = fold[j] - wg_a;
+              wg_a += d * (nb / nt);
+              wg_c += fold[256 + j] + d * d * (wg_n * nb / nt);
+              wg_n = nt;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int q = 0; q < PPI; ++q) {
+            wg_a += fold[w * 64 + q * SQ + tid];
+            wg_c += fold[256 + w * 64 + q * SQ + tid];
+          }
+      }
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + 4 * tid) = wg_a;
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + 4 * tid) = wg_c;
+    }
   }
 }
 
