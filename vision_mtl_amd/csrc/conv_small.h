@@ -70,6 +70,16 @@ struct SmallP {
   int dbg;  // tuning aid (VMTL_SMALL_DBG): 1 skip the output stores, 2 skip halo staging, 4 skip the MFMA loop, 8 no start skew
 };
 
+// Workgroup barrier for LDS hand-overs only.  __syncthreads() is also a global-memory fence: it drains vmcnt, i.e.
+// waits for every outstanding global STORE (the previous tile's output rows, the a_out rows) and prefetch load at
+// each of the five barriers of a tile - measured as 26 % of the wave cycles parked, matrix pipe 69 % busy at two
+// waves per SIMD.  Nothing another wave reads through global memory is produced inside the tile loop, so the
+// barrier only has to order LDS traffic: wait for this wave's LDS operations, then s_barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// per-CU arrival tickets (index: XCC id << 8 | SE/SH/CU id), see the start-skew note in the kernel
+static __device__ int g_small_cu_ticket[4096];
+
 template <int CS, int TN, int NT>
 struct SmallCfg {
   static constexpr int SP = CS / 4;         // channel quads per pixel
@@ -232,12 +242,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // overlap.  The second half of the grid (dispatched after every CU has its first workgroup) starts half a tile
   // period late, so one workgroup's staging / epilogue falls into the other's K loop.  Timing only.
   {
-    const int mode = (p.dbg >> 3) & 3;  // tuning aid: 0 upper half of the grid, 1 nobody, 2 odd XCD-local ids, 3 odd ids
-    const bool late = mode == 0 ? blockIdx.x >= (gridDim.x + 1) / 2 : (mode == 2 ? (blockIdx.x >> 3) & 1 : (mode == 3 ? blockIdx.x & 1 : false));
-    if (late) {
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(40);
+    // CU-exact pairing: the hardware id of the CU this workgroup landed on (XCC, SE, SH, CU) indexes a ticket counter;
+    // the second workgroup to arrive on a CU (odd ticket) starts half a tile period late.  Tickets are never reset:
+    // with two workgroups per CU and launch the parity alternates by itself.
+    const int mode = (p.dbg >> 3) & 3;  // tuning aid: 0 ticket per CU, 1 nobody, 2 upper half of the grid, 3 odd ids
+    int late = 0;
+    if (tid == 0) {
+      if (mode == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);   // HW_ID[15:0]: cu_id [11:8], sh_id [12], se_id [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);  // XCC_ID[3:0]
+        const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+        late = atomicAdd(&g_small_cu_ticket[key], 1) & 1;
+      } else {
+        late = mode == 2 ? blockIdx.x >= (gridDim.x + 1) / 2 : (mode == 3 ? blockIdx.x & 1 : 0);
+      }
+      if (late) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(40);
+      }
     }
+    // the other waves wait for wave 0 at the first barrier of the tile loop
   }
   // statistics accumulated over this workgroup's tiles (threads tid < SQ own one channel quad each)
   f32x4 wg_a = {0.f, 0.f, 0.f, 0.f}, wg_c = wg_a;
@@ -256,9 +280,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   for (; t < p.ntiles; t += gridDim.x) {
     const int b = nb, h0 = nh0, w0 = nw0;
-    __syncthreads();  // every wave is done with the previous tile's LDS image (first pass: weights / coef are in LDS)
+    lds_barrier();  // every wave is done with the previous tile's LDS image (first pass: weights / coef are in LDS)
     if (!(p.dbg & 2)) stage_store(b, h0, w0);
-    __syncthreads();
+    lds_barrier();
     if (t + (int)gridDim.x < p.ntiles && !(p.dbg & 2)) {  // global loads stay in flight under the MFMAs
       tile_origin(t + gridDim.x, nb, nh0, nw0);
       prefetch(nb, nh0, nw0);
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int tt = 0; tt < NTT; ++tt) tacc[i][tt] = (f32x2){0.f, 0.f};
     }
     // fragments of one k-group: A (TM pixel tiles), B (TN weight-row tiles), tail weight rows
-    struct Frag { f32x4 a[TM], b[TN]; int ti; };
+    struct Frag { f32x4 a[TM], b[TN], t[NTT]; };
     auto load_frag = [&](int g, Frag& f) {
       int ai, bi, ti;
       if (g < NGF) {
@@ -310,15 +334,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) f.b[j] = wm[bi + 16 * j];
-      f.ti = ti;
+      if (NT > 0) {  // tail weight rows (wave-uniform row, one k quad per lane quarter)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) f.t[tt] = wt[ti + tt];
+      }
     };
     auto mma_frag = [&](const Frag& f) {
-      // tail weight rows (wave-uniform row, one k quad per lane quarter): read now, consumed after the MFMAs
-      f32x4 ft[NTT];
-      if (NT > 0) {
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) ft[tt] = wt[f.ti + tt];
-      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -329,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (NT > 0) {
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-          const f32x2 lo = __builtin_shufflevector(ft[tt], ft[tt], 0, 1), hi = __builtin_shufflevector(ft[tt], ft[tt], 2, 3);
+          const f32x2 lo = __builtin_shufflevector(f.t[tt], f.t[tt], 0, 1), hi = __builtin_shufflevector(f.t[tt], f.t[tt], 2, 3);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             tacc[i][tt] += __builtin_shufflevector(f.a[i], f.a[i], 0, 1) * lo;
@@ -341,8 +362,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     };
-    // software pipeline: the LDS reads of group g+1 are issued before the MFMAs of group g; the scheduling barrier
-    // keeps the compiler from hoisting ALL groups' reads to the top (which spilled: 21 groups x 12 fragments)
+    // software pipeline: the LDS reads of group g+1 are issued before the MFMAs of group g.  The order inside a group
+    // is pinned (all reads of g+1, then the MFMAs of g, then the tail FMAs): left to itself the scheduler put the B
+    // reads at the END of the group and the tail read + its FMAs at the start, i.e. two exposed LDS latencies per
+    // 16 MFMAs (matrix pipe measured 69 % busy at two waves per SIMD); the barrier at the end keeps it from hoisting ALL
+    // groups' reads to the top (which spilled: 21 groups x 12 fragments).
     Frag fr[2];
     load_frag(0, fr[0]);
     if (!(p.dbg & 4))
@@ -350,6 +374,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int g = 0; g < NGF + NGR; ++g) {
       if (g + 1 < NGF + NGR) load_frag(g + 1, fr[(g + 1) & 1]);
       mma_frag(fr[g & 1]);
+      if (g + 1 < NGF + NGR) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN + NT, 0);  // DS reads of g+1
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);                         // MFMAs of g
+      __builtin_amdgcn_sched_group_barrier(0x002, 4 * TM * NT + 8, 0);                     // tail FMAs (+ address VALU)
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // NHWC: C layout -> LDS output tile (the halo region; every wave must be out of the K loop first) -> each
     // lane moves float4 (pixel, channel quad) rows of the wave's own 32 pixels: fully coalesced global accesses
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -460,7 +487,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // per-tile column sums: lane partials -> LDS -> the first SQ threads add the 4 x PPI partials of their quad
       red[wv * 64 + lane] = s1;
       red[256 + wv * 64 + lane] = s2;
-      __syncthreads();
+      lds_barrier();
       if (p.ep_mode == 1) {
         // (mean, M2): the tile mean first (statistics are only enabled for full tiles: 128 pixels), M2 around it
         constexpr float inv_n = 1.f / (float)(CSM_TH * CSM_TW);
@@ -477,7 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int it = 0; it < EIT; ++it)
           if (elane && it * PPI + epl < CSM_TW) q2 += (val[it] - m) * (val[it] - m);
         red[256 + wv * 64 + lane] = q2;
-        __syncthreads();
+        lds_barrier();
         if (tid < SQ && 4 * tid < p.ldy) {
           f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
