@@ -73,11 +73,11 @@ def conv_bn_act(x: Act, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | N
 
 
 def bn_act(x: Act, bn: nn.BatchNorm2d, act: int, mul: Act | None = None, res: Act | None = None,
-           stats=None) -> Act:
+           stats=None, stats_rpb: int = 0) -> Act:
     momentum = _momentum(bn)
     y = ops.bn_act(x.t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, x.C,
                    bn.training, momentum, bn.eps, act, mul=None if mul is None else mul.t,
-                   res=None if res is None else res.t, stats=stats)
+                   res=None if res is None else res.t, stats=stats, stats_rpb=stats_rpb)
     return Act(y, x.C)
 
 

@@ -274,7 +274,7 @@ class UnetDecoder(nn.Module):
                 return L.Act(raw, C), st, rpb
             raw, st, rpb = ops.bn_act_conv(raw, st, rpb, bn, C, ACT_RELU, c2.weight, want_stats=bn2.training)
             bn, C = bn2, c2.out_channels
-        return L.bn_act(L.Act(raw, C), bn, ACT_RELU, stats=st)
+        return L.bn_act(L.Act(raw, C), bn, ACT_RELU, stats=st, stats_rpb=rpb)
 
 
 class Activation(nn.Module):

@@ -37,7 +37,15 @@ class DoubleConv(nn.Module):
 
     def run(self, x: L.Act) -> L.Act:
         s = self.double_conv
-        return L.conv_bn_act(L.conv_bn_act(x, s[0], s[1], ACT_RELU), s[3], s[4], ACT_RELU)
+        ops = L.ops
+        # conv -> [BN + ReLU + conv as ONE pre-activation node: the second conv's data gradient ends with the first
+        # BatchNorm's backward reduction] -> BN + ReLU
+        out = ops.conv2d(x.t, s[0].weight, None, 1, 1, want_stats=s[1].training)
+        y1, st1 = out if s[1].training else (out, None)
+        rpb1 = getattr(st1, "_vmtl_rpb", 0) if st1 is not None else 0
+        y2, st2, rpb2 = ops.bn_act_conv(y1, st1, rpb1, s[1], s[0].out_channels, ACT_RELU, s[3].weight,
+                                        want_stats=s[4].training)
+        return L.bn_act(L.Act(y2, s[3].out_channels), s[4], ACT_RELU, stats=st2, stats_rpb=rpb2)
 
     def forward(self, x):
         if isinstance(x, L.Act):
