@@ -197,7 +197,8 @@ class _PackCache:
         self.custom = {}   # key -> dict(dst, fn, wref, ptr, version, epoch): operands with their own pack kernel
         self.shared_bufs = {}  # key -> (weakref of the anchoring weight, buffer)
         self.epoch = 0
-        self.table = None  # (device uint8 tensor, n, total)
+        self.table = None  # (device uint8 tensor, n, total): entries packed on the main stream
+        self.table_side = None  # the large entries, packed on the side stream
         self.live = []
         self.dirty = True
         self.custom_ready = None  # event: this step's custom operands are packed (side stream)
@@ -227,6 +228,8 @@ class _PackCache:
         if e is not None and e["wref"]() is not weight:  # id() of a dead tensor reused by a new one
             e = None
         if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
+            if e.get("side"):
+                self.join()  # packed on the side stream this step: wait for its event (no-op after the first time)
             return e["dst"]
         R1, R0, T, C, Cs = params[:5]
         if e is None or e["ptr"] != weight.data_ptr() or (out is not None and e["dst"].data_ptr() != out.data_ptr()):
@@ -272,24 +275,36 @@ class _PackCache:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    # entries at least this large are packed on the SIDE stream (second table): the decoder's operands are 50 of the
+    # 54 MB and are not needed before the encoder has run (~1.5 ms into the step); packing them on the main stream put
+    # 0.12 ms in front of the first conv
+    SIDE_TABLE_MIN_ELEMS = 1 << 18
+
     def _build_table(self):
         import struct
 
+        def table(live):
+            if not live:
+                return None
+            recs, start = [], 0
+            for e in live:
+                R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
+                recs.append(struct.pack("<QQqqqqqiiiiii", e["ptr"] + 4 * e.get("offset", 0), e["dst"].data_ptr(), sr1, sr0,
+                                        st, sc, start, R1, R0, T, C, Cs, flip))
+                start += R1 * R0 * T * Cs
+            size = lib().raw("vmtl_pack_desc_bytes")()
+            blob = b"".join(r.ljust(size, b"\0") for r in recs)
+            dev = live[0]["dst"].device
+            return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), len(recs), start
+
         live = list(self.entries.values())
-        if not live:
-            self.table, self.live, self.dirty = None, [], False
-            return
-        recs, start = [], 0
+        big = lambda e: e["params"][0] * e["params"][1] * e["params"][2] * e["params"][4] >= self.SIDE_TABLE_MIN_ELEMS
         for e in live:
-            R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
-            recs.append(struct.pack("<QQqqqqqiiiiii", e["ptr"] + 4 * e.get("offset", 0), e["dst"].data_ptr(), sr1, sr0,
-                                    st, sc, start, R1, R0, T, C, Cs, flip))
-            start += R1 * R0 * T * Cs
-        size = lib().raw("vmtl_pack_desc_bytes")()
-        blob = b"".join(r.ljust(size, b"\0") for r in recs)
-        dev = live[0]["dst"].device
-        table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-        self.table, self.live, self.dirty = (table, len(recs), start), live, False
+            e["side"] = bool(side.enabled and big(e))
+        self.live = live
+        self.table = table([e for e in live if not e["side"]])
+        self.table_side = table([e for e in live if e["side"]])
+        self.dirty = False
 
     def refresh(self):
         """Re-pack every known weight (call once at the start of a step, before the forward)."""
@@ -307,13 +322,14 @@ class _PackCache:
         if self.table is not None:
             table, n, total = self.table
             _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
-            for e in self.live:
-                w = e["wref"]()
-                if w is not None:
-                    e["version"], e["epoch"] = w._version, self.epoch
-        # operands with their own pack kernels (up2 phase / gradient matrices): none is needed before the
-        # decoder, so they are built on the side stream while the encoder runs
-        if self.custom:
+        for e in self.live:
+            w = e["wref"]()
+            if w is not None:
+                e["version"], e["epoch"] = w._version, self.epoch
+        # the large operands and the ones with their own pack kernels (up2 phase / gradient matrices): none is needed
+        # before the decoder, so they are built on the side stream while the encoder runs; get() / get_custom() make
+        # the consuming stream wait for the event on first use
+        if self.custom or self.table_side is not None:
             use_side = side.enabled
             if use_side:
                 main = torch.cuda.current_stream()
@@ -323,6 +339,9 @@ class _PackCache:
             else:
                 ctx = contextlib.nullcontext()
             with ctx:
+                if self.table_side is not None:
+                    table, n, total = self.table_side
+                    _k("vmtl_pack_weights_batch", descs=table, n=n, total=total)
                 for e in self.custom.values():
                     w = e["wref"]()
                     if w is None:
