@@ -118,6 +118,15 @@ int vmtl_conv3x3_small(const float* x, const float* x2, const float* pa, const f
 /* depthwise KxK (K in {3,5}, stride in {1,2}); wp is packed [K*K][Cs]. */
 int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B, int H, int W, int Cs, int Ho, int Wo,
                     int K, int stride, int pad, void* stream);
+/* depthwise conv as a pre-activation node: v = act(coef_a[c]*x + coef_c[c]) applied to the taps while loading (the
+ * BatchNorm + activation of the pointwise conv that produced x; coefficients from vmtl_bn_stats_coef), y = dwconv(v),
+ * a_out (optional) = v, partial (optional) = [vmtl_dwconv_bn_stats_rows(M, Cs)][2][Cs] (mean, M2) rows of y over
+ * vmtl_dwconv_bn_stats_block(M, Cs) output pixels each, M = B*Ho*Wo.  pad must be (K-1)/2. */
+int vmtl_dwconv_bn_stats_rows(int M, int Cs);
+int vmtl_dwconv_bn_stats_block(int M, int Cs);
+int vmtl_dwconv_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act, const float* wp, float* y,
+                       float* a_out, float* partial, int B, int H, int W, int Cs, int Ho, int Wo, int K, int stride,
+                       int pad, void* stream);
 int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
                          int Wo, int K, int stride, int pad, void* stream);
 int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,

@@ -269,3 +269,55 @@ def test_bn_act_conv_matches_torch(dev, case, training):
         assert_close(from_dev_nhwc(skd.grad, C1), skr.grad, tol=2e-4, what="bn_act_conv dskip")
     assert_close(bnd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
     assert_close(bnd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")
+
+
+# B, C, H, W, K, stride, act
+BNDW_CASES = [(2, 64, 16, 24, 3, 2, "relu"), (2, 72, 12, 20, 5, 2, "relu"), (1, 120, 9, 7, 5, 1, "relu"),
+              (2, 200, 8, 8, 3, 1, "hardswish"), (1, 960, 4, 8, 5, 1, "hardswish"), (3, 24, 15, 17, 3, 2, "relu")]
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("case", BNDW_CASES)
+def test_bn_act_dwconv_matches_torch(dev, case, training):
+    """ops.bn_act_dwconv (BatchNorm + activation applied while the depthwise taps load, output statistics from the
+    same pass) == depthwise_conv(act(bn(x))) in torch: values, output statistics, every gradient."""
+    import copy
+
+    from vision_mtl_amd import ops
+
+    B, C, H, W, K, stride, act = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g) * 0.2
+    bn.running_mean.data = torch.randn(C, generator=g) * 0.1
+    bn.running_var.data = torch.rand(C, generator=g) + 0.5
+    bn.train(training)
+    bnd = copy.deepcopy(bn).to(dev)
+    w = torch.randn(C, 1, K, K, generator=g) / K
+    fact = {"relu": F.relu, "hardswish": F.hardswish}[act]
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(fact(bn(xr)), wr, None, stride=stride, padding=(K - 1) // 2, groups=C)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    y, stats, rpb = ops.bn_act_dwconv(xd, None, 0, bnd, C, ops.ACT_CODES[act], wd, stride, (K - 1) // 2, want_stats=True)
+    assert_close(from_dev_nhwc(y, C), yr.detach(), what="bn_act_dwconv fwd")
+    assert float(y[..., C:].abs().sum()) == 0.0 if y.shape[-1] > C else True
+    st = stats.cpu().double()
+    M = yr.shape[0] * yr.shape[2] * yr.shape[3]
+    cnt = torch.tensor([max(0, min(rpb, M - i * rpb)) for i in range(st.shape[0])], dtype=torch.float64).view(-1, 1)
+    mean = (st[:, 0, :C] * cnt).sum(0) / M
+    var = ((st[:, 1, :C] + cnt * (st[:, 0, :C] - mean) ** 2) * (cnt > 0)).sum(0) / M
+    yo = yr.detach().double()
+    assert_close(mean, yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="dw output stats mean")
+    assert_close(var, yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="dw output stats var")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=2e-4, what="bn_act_dwconv dx")
+    assert_close(wd.grad.cpu(), wr.grad, tol=2e-4, what="bn_act_dwconv dw")
+    assert_close(bnd.weight.grad.cpu(), bn.weight.grad, tol=2e-4, what="bn_act_dwconv dgamma")
+    assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="bn_act_dwconv dbeta")
+    assert_close(bnd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
+    assert_close(bnd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")

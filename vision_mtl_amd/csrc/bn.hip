@@ -21,15 +21,6 @@ extern "C" int vmtl_reduce_rows(int M) { return red_blocks(M); }
 // Per-block partial rows are (mean_b, M2_b) over the block's rows, merged by Chan's formula in
 // fp64 (never E[x^2] - E[x]^2).  Each thread accumulates SHIFTED sums around the first value it
 // sees, which keeps fp32 accurate even when |mean| >> std.
-__device__ __forceinline__ void chan_merge(float& n, f32x4& mean, f32x4& m2, float nb, f32x4 mb, f32x4 m2b) {
-  if (nb <= 0.f) return;
-  const float nt = n + nb;
-  const f32x4 d = mb - mean;
-  mean += d * (nb / nt);
-  m2 += m2b + d * d * (n * nb / nt);
-  n = nt;
-}
-
 __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const float* __restrict__ x, int M, int Cs,
                                                                float* partial) {
   __shared__ f32x4 red_mean[RED_THREADS];

@@ -7,6 +7,8 @@
 // blocks reached from reference vision_mtl/utils/model_utils.py:25-34 (smp.Unet encoder) [3P].
 //
 // Weights are consumed in packed [tap][Cs] form (see pack.hip).
+#include <stdlib.h>
+
 #include "reduce.h"
 
 #define DW_MAX_TAPS 25
@@ -33,6 +35,85 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict
       }
     }
     reinterpret_cast<f32x4*>(y)[i] = acc;
+  }
+}
+
+// Depthwise conv as a PRE-ACTIVATION node: the input is the RAW output of the preceding pointwise conv, its
+// BatchNorm + activation (timm InvertedResidual: conv_pw -> bn1 -> act -> conv_dw -> bn2, reached from reference
+// utils/model_utils.py:25-34) is applied while the taps are loaded (v = act(ca[c] * x + cc[c]); zero padding applies
+// to v), and the BatchNorm (mean, M2) partial rows of the OUTPUT come from the same pass - the separate apply and
+// statistics launches (2 of the ~14 launches of a block's forward) disappear.  a_out (optional) receives the
+// activated input for the weight-gradient kernel: input pixel (h, w) is written by the one tap that owns it
+// (dh = pad + h % stride, dw = pad + w % stride, i.e. the centre tap for stride 1).
+// Threads keep ONE channel quad and sweep output pixels (reduce.h mapping); one partial row per workgroup.
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void dwconv_bn_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ ca, const float* __restrict__ cc, const float* __restrict__ wp,
+    float* __restrict__ y, float* __restrict__ a_out, float* __restrict__ partial, int H, int W, int Cs, int Ho, int Wo, int K,
+    int stride, int pad, int M) {
+  __shared__ f32x4 red_mean[RED_THREADS];
+  __shared__ f32x4 red_m2[RED_THREADS];
+  __shared__ float red_n[RED_THREADS];
+  const int CQ = Cs >> 2;
+  const int nblk = gridDim.x;
+  const int rows_per_blk = (M + nblk - 1) / nblk;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int T = rpt * cq;
+    const int t = threadIdx.x;
+    const int q = q0 + t % cq, ro = t / cq;
+    f32x4 K0 = {0.f, 0.f, 0.f, 0.f}, s1 = K0, s2 = K0;
+    float n = 0.f;
+    if (t < T) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(ca + (size_t)q * 4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(cc + (size_t)q * 4);
+      for (int r = r_begin + ro; r < r_end; r += rpt) {
+        const int wo = r % Wo, ho = (r / Wo) % Ho, b = r / (Wo * Ho);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int dh = 0; dh < K; ++dh) {
+          const int h = ho * stride - pad + dh;
+          if ((unsigned)h >= (unsigned)H) continue;
+          for (int dw = 0; dw < K; ++dw) {
+            const int w = wo * stride - pad + dw;
+            if ((unsigned)w >= (unsigned)W) continue;
+            const size_t off = ((size_t)(b * H + h) * W + w) * Cs + (size_t)q * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + off) * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACT);
+            acc += v * *reinterpret_cast<const f32x4*>(wp + (size_t)(dh * K + dw) * Cs + (size_t)q * 4);
+            if (a_out != nullptr && dh == pad + h % stride && dw == pad + w % stride)
+              *reinterpret_cast<f32x4*>(a_out + off) = v;
+          }
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)r * Cs + (size_t)q * 4) = acc;
+        if (n == 0.f) K0 = acc;  // shifted sums around the first value: accurate when |mean| >> std
+        const f32x4 d = acc - K0;
+        s1 += d;
+        s2 += d * d;
+        n += 1.f;
+      }
+    }
+    if (partial == nullptr) continue;
+    f32x4 mean = K0, m2 = {0.f, 0.f, 0.f, 0.f};
+    if (n > 0.f) {
+      mean = K0 + s1 * (1.f / n);
+      m2 = s2 - s1 * s1 * (1.f / n);
+    }
+    __syncthreads();
+    red_mean[t] = mean;
+    red_m2[t] = m2;
+    red_n[t] = t < T ? n : 0.f;
+    __syncthreads();
+    if (t < cq) {
+      float nt = red_n[t];
+      f32x4 mt = red_mean[t], m2t = red_m2[t];
+      for (int j = 1; j < rpt; ++j) chan_merge(nt, mt, m2t, red_n[t + j * cq], red_mean[t + j * cq], red_m2[t + j * cq]);
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * Cs + (size_t)(q0 + t) * 4) = mt;
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * Cs + (size_t)(q0 + t) * 4) = m2t;
+    }
   }
 }
 
@@ -173,6 +254,50 @@ extern "C" int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B,
   const long long total4 = (long long)B * Ho * Wo * (Cs >> 2);
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(dw_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, wp, y, B, H, W,
                      Cs, Ho, Wo, K, stride, pad, total4);
+  return vmtl_check_launch();
+}
+
+// rows of the statistics tensor the fused forward writes ([rows][2][Cs]); every row covers vmtl_dwconv_bn_stats_block
+// output pixels (the last one fewer)
+// Workgroups (= statistics rows) of the fused forward.  A thread keeps one channel quad and walks
+// rows_per_blk / (256 / quads) output pixels x K*K taps serially, so - unlike the pure reductions, which use
+// red_blocks() - the row blocks must stay SHORT for the deep layers (M = 1024 pixels x 240 quads left 64 workgroups
+// of 16 serial pixels each: slower than the three launches it replaces): two pixels per thread, at most 1024 rows.
+static int dwbn_blocks(int M, int Cs) {
+  const int cq = Cs >> 2;
+  const int rpt = cq >= RED_THREADS ? 1 : RED_THREADS / cq;
+  static int per_thread = -1;
+  if (per_thread < 0) {
+    const char* e = getenv("VMTL_DWBN_ROWS");  // tuning aid: output pixels per thread
+    per_thread = e ? atoi(e) : 2;
+    if (per_thread < 1) per_thread = 1;
+  }
+  int rows = per_thread * rpt;
+  if (rows < cdiv(M, 1024)) rows = cdiv(M, 1024);
+  return cdiv(M, rows);
+}
+extern "C" int vmtl_dwconv_bn_stats_rows(int M, int Cs) { return dwbn_blocks(M, Cs); }
+extern "C" int vmtl_dwconv_bn_stats_block(int M, int Cs) { return cdiv(M, dwbn_blocks(M, Cs)); }
+
+extern "C" int vmtl_dwconv_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act, const float* wp,
+                                  float* y, float* a_out, float* partial, int B, int H, int W, int Cs, int Ho, int Wo, int K,
+                                  int stride, int pad, void* stream) {
+  VMTL_ENTER();
+  if (!x || !coef_a || !coef_c || !wp || !y) return VMTL_ERR_ARG;
+  if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
+  if (pad != (K - 1) / 2) return VMTL_ERR_ARG;  // the a_out ownership rule assumes "same"-style padding
+  const int M = B * Ho * Wo;
+  const int nblk = dwbn_blocks(M, Cs);
+#define CALL(A)                                                                                                       \
+  hipLaunchKernelGGL((dwconv_bn_fwd_kernel<A>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream, x, coef_a, coef_c, \
+                     wp, y, a_out, partial, H, W, Cs, Ho, Wo, K, stride, pad, M)
+  switch (act) {
+    case VMTL_ACT_NONE: CALL(VMTL_ACT_NONE); break;
+    case VMTL_ACT_RELU: CALL(VMTL_ACT_RELU); break;
+    case VMTL_ACT_HSWISH: CALL(VMTL_ACT_HSWISH); break;
+    default: return VMTL_ERR_ARG;
+  }
+#undef CALL
   return vmtl_check_launch();
 }
 

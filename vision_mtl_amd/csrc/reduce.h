@@ -223,3 +223,13 @@ static inline int sweep_blocks(long long M, int Cs) {
   if (nb < 1) nb = 1;
   return (int)nb;
 }
+
+// Chan's parallel merge of (count, mean, M2) per channel quad: (n, mean, m2) <- merged with (nb, mb, m2b)
+__device__ __forceinline__ void chan_merge(float& n, f32x4& mean, f32x4& m2, float nb, f32x4 mb, f32x4 m2b) {
+  if (nb <= 0.f) return;
+  const float nt = n + nb;
+  const f32x4 d = mb - mean;
+  mean += d * (nb / nt);
+  m2 += m2b + d * d * (n * nb / nt);
+  n = nt;
+}

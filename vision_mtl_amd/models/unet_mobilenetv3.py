@@ -118,8 +118,20 @@ class InvertedResidual(nn.Module):
         self.drop_path = nn.Identity()
 
     def run(self, x: L.Act) -> L.Act:
-        y = L.conv_bn_act(x, self.conv_pw, self.bn1, self.bn1.act_code)
-        y = L.conv_bn_act(y, self.conv_dw, self.bn2, self.bn2.act_code)
+        ops = L.ops
+        if ops.FUSE_DW and self.bn1.act_code in (ACT_NONE, ACT_RELU, ACT_HSWISH):
+            # conv_pw -> [bn1 + act + conv_dw as one pre-activation node, bn2's statistics from its epilogue] -> bn2 + act
+            train = self.bn1.training
+            out = ops.conv2d(x.t, self.conv_pw.weight, None, 1, 0, want_stats=train)
+            raw1, st1 = out if train else (out, None)
+            rpb1 = getattr(st1, "_vmtl_rpb", 0) if st1 is not None else 0
+            dw = self.conv_dw
+            raw2, st2, rpb2 = ops.bn_act_dwconv(raw1, st1, rpb1, self.bn1, dw.out_channels, self.bn1.act_code, dw.weight,
+                                                L._pair(dw.stride), L._pair(dw.padding), want_stats=self.bn2.training)
+            y = L.bn_act(L.Act(raw2, dw.out_channels), self.bn2, self.bn2.act_code, stats=st2, stats_rpb=rpb2)
+        else:
+            y = L.conv_bn_act(x, self.conv_pw, self.bn1, self.bn1.act_code)
+            y = L.conv_bn_act(y, self.conv_dw, self.bn2, self.bn2.act_code)
         if isinstance(self.se, SqueezeExcite):
             y = self.se.run(y)
         return L.conv_bn_act(y, self.conv_pwl, self.bn3, ACT_NONE, res=x if self.has_skip else None)

@@ -387,6 +387,7 @@ def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
     return out
 
 
+FUSE_DW = os.environ.get("VMTL_FUSE_DW", "1") != "0"  # encoder: bn1 + act + depthwise conv as one node (vmtl_dwconv_bn_fwd)
 _PW = os.environ.get("VMTL_PW", "1") != "0"  # pointwise GEMM kernel for 1x1 convs (csrc/conv_pw.hip)
 _PW_MAX_ROWS = int(os.environ.get("VMTL_PW_MAX_ROWS", str(1 << 21)))  # measured on MTAN (M = 2^20): 57.1 -> 55.5 ms/step
 
@@ -872,6 +873,84 @@ class _DwConv(torch.autograd.Function):
             if ctx.slot is not None:
                 dw = None
         return dx, dw, None, None
+
+
+class _BNActDw(torch.autograd.Function):
+    """(y, stats) = dwconv(act(BN(x))): timm InvertedResidual's conv_pw -> bn1 -> act -> conv_dw boundary (reference
+    utils/model_utils.py:25-34 [3P]) as a pre-activation node.  x is the RAW pointwise-conv output with its BatchNorm
+    partial rows; normalise + activation run while the depthwise taps are loaded and the output's own BatchNorm
+    partial rows come from the same pass (vmtl_dwconv_bn_fwd): two launches fewer per block than apply / dwconv /
+    statistics sweep.  The activated input is written back once (a) for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, stats, rpb, gamma, beta, rm, rv, nbt, weight, cfg):
+        C, training, momentum, eps, act, stride, pad, want_stats = cfg
+        x, weight = _req(x, "x"), _req(weight, "weight")
+        B, H, W, Cs = x.shape
+        Cw, one, K, K2 = weight.shape
+        if one != 1 or K != K2 or Cw != C or ceil4(C) != Cs or pad != (K - 1) // 2:
+            raise ValueError("bn_act_dwconv: weight must be (C, 1, K, K) over x's channels with pad (K-1)//2")
+        Ho = (H + 2 * pad - K) // stride + 1
+        Wo = (W + 2 * pad - K) // stride + 1
+        mean, invstd, ca, cc = _bn_fwd_coef(x, stats, rpb, gamma, beta, rm, rv, nbt, C, training, momentum, eps)
+        wp = packs.get(weight, "dw", (1, 1, K * K, C, Cs, 0, 0, 1, K * K, 0))
+        need_bwd = any(ctx.needs_input_grad)
+        a = _empty(x.shape, x) if need_bwd else None
+        y = _empty((B, Ho, Wo, Cs), x)
+        ostats = None
+        if want_stats:
+            ostats = _empty((lib().raw("vmtl_dwconv_bn_stats_rows")(B * Ho * Wo, Cs), 2, Cs), x)
+        _k("vmtl_dwconv_bn_fwd", x=x, coef_a=ca, coef_c=cc, act=act, wp=wp, y=y, a_out=a, partial=ostats, B=B, H=H, W=W,
+           Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
+        ctx.save_for_backward(x, a, weight, wp, mean, invstd, gamma, beta)
+        ctx.cfg = (C, training, act, stride, pad)
+        ctx.slots = (_slot(gamma), _slot(beta), _slot(weight))
+        ctx.set_materialize_grads(False)
+        if ostats is not None:
+            ctx.mark_non_differentiable(ostats)
+        return y, ostats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, a, weight, wp, mean, invstd, gamma, beta = ctx.saved_tensors
+        C, training, act, stride, pad = ctx.cfg
+        sg, sb, sw = ctx.slots
+        if dy is None:
+            return (None,) * 10
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        K = weight.shape[2]
+        _, Ho, Wo, _ = dy.shape
+        M = B * H * W
+        stamp(f"main bndw M={B * Ho * Wo} C={C}")
+        fork = side.mark()
+        da = _empty(x.shape, x)
+        _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=da, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
+        dgamma = _empty((C,), x) if sg is None else sg
+        dbeta = _empty((C,), x) if sb is None else sb
+        dx = _empty(x.shape, x)
+        part = _empty((_reduce_rows(M), 2, Cs), x)
+        _k("vmtl_bn_bwd", x=x, dy=da, mean=mean, invstd=invstd, gamma=gamma, beta=beta, mul=None, dmul=None, partial=part,
+           sum_dz=dbeta, sum_dzx=dgamma, dx=dx, M=M, C=C, Cs=Cs, act=act, training=1 if training else 0)
+        dw = _empty(weight.shape, x) if sw is None else sw
+        with side.branch(sw is not None, B * Ho * Wo, fork, a, dy):
+            partial = _empty((256, K * K, Cs), x)
+            _k("vmtl_dwconv_bwd_weight", x=a, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo, K=K,
+               stride=stride, pad=pad)
+            stamp(f"side bndw C={C}")
+        nif = lambda g, slot: None if slot is not None else g
+        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), None
+
+
+def bn_act_dwconv(x, stats, rpb, bn, C, act, weight, stride=1, pad=1, want_stats=True):
+    """(y_raw, stats, rows_per_block) = dwconv(act(bn(x_raw))); bn = the nn.BatchNorm2d container of x's layer."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
+    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, stride, pad, bool(want_stats))
+    y, ostats = _BNActDw.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               bn.num_batches_tracked, weight, cfg)
+    orpb = lib().raw("vmtl_dwconv_bn_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3]) if ostats is not None else 0
+    return y, ostats, orpb
 
 
 def dwconv(x, weight, stride=1, pad=1):
