@@ -298,6 +298,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     ci += k_begin * BK;
     normalize();
   }
+  // tail columns that hold real weight rows (the others multiply zeros): wave-uniform
+  const int ntc = NT > 0 ? max(0, min(NT, p.Nw - (n0 + BNM))) : 0;
   // one BK chunk of MFMAs (+ VALU tail columns) on staging buffer `cur`
   auto compute = [&](int cur) {
     if constexpr (X3) {
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         // tail weight rows BNM + t (wave-uniform row, per-quarter k slot): 4 distinct LDS addresses
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+          if (t >= ntc) break;  // weight rows past Nw are zero: skip their FMAs (33 outputs = 32 MFMA columns + ONE tail)
           const f32x4 ft = *reinterpret_cast<const f32x4*>(Bs + cur * BNR * LDT + (BNM + t) * LDT +
                                                            (((kg * 4 + lq) ^ ((BNM + t) & 7)) * 4));
           const f32x2 ft_lo = __builtin_shufflevector(ft, ft, 0, 1), ft_hi = __builtin_shufflevector(ft, ft, 2, 3);
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) tacc[t][j] = 0.f;
 
+  const int ntr = NTR > 0 ? max(0, min(NTR, p.Nw - (co0 + BMM))) : 0;
   if (p_begin < p_end) {
     load_tile(p_begin);
     store_tile(0);
@@ -851,9 +855,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       if (NTR > 0) {  // dY[pixel 4s+lq][BMM .. BMM+3]: one 16-byte LDS read, broadcast within the quarter
         const f32x4 ty = *reinterpret_cast<const f32x4*>(Ys + cur * BP * LDY + (4 * s + lq) * LDY + BMM);
 #pragma unroll
-        for (int t = 0; t < NTR; ++t)
+        for (int t = 0; t < NTR; ++t) {
+          if (t >= ntr) break;  // dY columns past Nw are zero pad lanes
 #pragma unroll
           for (int j = 0; j < TN; ++j) tacc[t][j] += ty[t] * fb[j];
+        }
       }
     }
     if (more) store_tile(cur ^ 1);
