@@ -248,6 +248,10 @@ long long vmtl_ce_workspace_bytes(long long P);
 /* element (b,c,hw) of logits / dlogits sits at [b*sb + c*sc + hw*sp] (NCHW: C*HW, HW, 1). */
 int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void* workspace, int B, int HW,
                 int C, long long sb, long long sc, long long sp, void* stream);
+/* the same, also writing argmax_c logits per pixel (the prediction of lit_module.py:137-138) */
+int vmtl_ce_fwd_argmax(const float* logits, const long long* target, float* loss, void* workspace,
+                       long long* argmax, int B, int HW, int C, long long sb, long long sc, long long sp,
+                       void* stream);
 int vmtl_ce_bwd(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
                 int HW, int C, long long sb, long long sc, long long sp, void* stream);
 /* as vmtl_ce_bwd with separate strides (dsb, dsc, dsp) for dlogits, e.g. NHWC (HW*ld, 1, ld) */

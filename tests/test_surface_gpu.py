@@ -339,3 +339,28 @@ def test_full_size_properties(dev, name, B, H, W, C):
         assert torch.isfinite(full[t]).all()
         assert_close(full[t][:2].cpu(), two[t].cpu(), tol=2e-5, what=f"{name} {t}: images 0-1 of the full batch vs a batch of 2")
         assert_close(two[t].cpu(), ref[t], tol=1e-4, what=f"{name} eval {t} at {H}x{W}")
+
+
+@pytest.mark.gpu
+def test_cross_entropy_with_argmax_matches_separate_ops():
+    """A18: the fused loss + prediction pass equals cross_entropy() and argmax_channels() (reference
+    lit_module.py:123 and 137-138), ties included, and its backward is the plain cross-entropy backward."""
+    from vision_mtl_amd import ops
+
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    for (B, C, H, W) in [(2, 19, 9, 13), (3, 13, 16, 32), (1, 5, 7, 3)]:
+        z = torch.randn(B, C, H, W, device=dev)
+        z[:, 1] = z[:, 3]  # ties: the first maximum wins
+        t = torch.randint(0, C, (B, H, W), device=dev)
+        z1, z2 = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        l1 = ops.cross_entropy(z1, t)
+        l2, pred = ops.cross_entropy_with_argmax(z2, t)
+        assert torch.equal(l1, l2)
+        assert torch.equal(pred, ops.argmax_channels(z))
+        assert torch.equal(pred.cpu(), z.cpu().argmax(dim=1))
+        l1.backward()
+        l2.backward()
+        assert torch.equal(z1.grad, z2.grad)
+        ref = torch.nn.functional.cross_entropy(z.cpu().double().requires_grad_(True), t.cpu())
+        assert abs(l2.item() - ref.item()) < 1e-5

@@ -68,53 +68,92 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const float* __re
   }
 }
 
+// fp64 sums of N values per thread over a 256-thread workgroup: out[i] (i < N) valid on every thread after the
+// call.  One barrier pair; fixed association order (run-to-run reproducible).
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&s)[N], double (*sh)[N] /* [4][N] */) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[i] += __shfl_xor(s[i], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) sh[threadIdx.x >> 6][i] = s[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) s[i] = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+}
+
 // mean / invstd from the (mean_b, M2_b) rows; block b covers rows [b*rows_per_blk, min(M, (b+1)*rows_per_blk)).
 // Optionally updates running stats the way torch does (momentum, unbiased variance).
+// This launch sits on the dependent chain of EVERY BatchNorm of the forward pass (56 per `basic` step), where its
+// cost is latency, not throughput: one workgroup per channel QUAD reads each row's (mean, M2) as two float4 (a
+// workgroup per channel fetched a 128-byte line for 4 useful bytes: 31 us for the 8192 rows of the full-resolution
+// convs), ONE pass (sums of n*(m - p) and M2 + n*(m - p)^2 about the pivot p = first row's mean, in fp64: the
+// variance is then s2/M - (s1/M)^2 with nothing to cancel), one barrier pair, and the per-channel parameters of
+// the four finishing lanes are requested before the reduction so their latency hides behind it.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int rows_per_blk,
                                                           int M, int C, int Cs, float eps, float momentum,
                                                           float* running_mean, float* running_var,
                                                           long long* num_batches_tracked, float* save_mean,
                                                           float* save_invstd, const float* gamma, const float* beta,
                                                           float* coef_a, float* coef_c) {
-  __shared__ double sh[4];
-  const int c = blockIdx.x;  // one workgroup per storage channel
-  if (c == 0 && threadIdx.x == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
-  if (c >= C) {
-    if (threadIdx.x == 0) {
-      save_mean[c] = 0.f;
-      save_invstd[c] = 0.f;
-      if (coef_a != nullptr) coef_a[c] = coef_c[c] = 0.f;
+  __shared__ double sh[4][8];
+  const int c0 = blockIdx.x * 4, t = threadIdx.x;
+  const int c = c0 + t;
+  const bool fin = t < 4 && c < C;
+  float g = 1.f, bt = 0.f, orm = 0.f, orv = 0.f;
+  if (fin) {
+    if (gamma != nullptr && coef_a != nullptr) g = gamma[c];
+    if (beta != nullptr && coef_a != nullptr) bt = beta[c];
+    if (running_mean != nullptr) {
+      orm = running_mean[c];
+      orv = running_var[c];
     }
+  }
+  if (blockIdx.x == 0 && t == 0 && num_batches_tracked != nullptr) num_batches_tracked[0] += 1;
+  const f32x4 pv = *reinterpret_cast<const f32x4*>(partial + c0);
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int b = t; b < nblk; b += 256) {
+    const int nb = max(0, min(rows_per_blk, M - b * rows_per_blk));
+    const float* row = partial + (size_t)b * 2 * Cs + c0;
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(row);
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + Cs);
+    const double n = (double)nb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double d = nb > 0 ? (double)m4[e] - (double)pv[e] : 0.0;  // rows past M may hold anything
+      s[e] += n * d;
+      s[4 + e] += (nb > 0 ? (double)q4[e] : 0.0) + n * d * d;
+    }
+  }
+  block_sum_n<8>(s, sh);
+  if (t >= 4 || c >= Cs) return;
+  if (!fin) {  // pad channel
+    save_mean[c] = 0.f;
+    save_invstd[c] = 0.f;
+    if (coef_a != nullptr) coef_a[c] = coef_c[c] = 0.f;
     return;
   }
-  auto rows_of = [&](int b) { return max(0, min(rows_per_blk, M - b * rows_per_blk)); };
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += blockDim.x)
-    s += (double)rows_of(b) * (double)partial[((size_t)b * 2 + 0) * Cs + c];
-  const double mean = block_sum(s, sh) / M;
-  double m2 = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
-    const double nb = rows_of(b);
-    if (nb > 0.0) {
-      const double d = (double)partial[((size_t)b * 2 + 0) * Cs + c] - mean;
-      m2 += (double)partial[((size_t)b * 2 + 1) * Cs + c] + nb * d * d;
-    }
-  }
-  m2 = block_sum(m2, sh);
-  if (threadIdx.x != 0) return;
-  double var = m2 / M;
+  const double dm = s[t] / M;
+  const double mean = (double)pv[t] + dm;
+  double var = s[4 + t] / M - dm * dm;
   if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const float fmean = (float)mean, fis = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = fmean;
+  save_invstd[c] = fis;
   if (coef_a != nullptr) {  // y = act(coef_a * x + coef_c): the normalisation as the consumer conv's prologue
-    const float sc = (gamma ? gamma[c] : 1.f) * save_invstd[c];
+    const float sc = g * fis;
     coef_a[c] = sc;
-    coef_c[c] = (beta ? beta[c] : 0.f) - save_mean[c] * sc;
+    coef_c[c] = bt - fmean * sc;
   }
   if (running_mean != nullptr) {
     const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    running_mean[c] = (float)((1.0 - momentum) * orm + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * orv + momentum * unb);
   }
 }
 
@@ -152,7 +191,7 @@ static int bn_stats_impl(const float* x, int M, int C, int Cs, float* partial, i
   } else if (rows_per_blk <= 0 || (long long)nblk * rows_per_blk < M) {
     return VMTL_ERR_ARG;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cs), dim3(256), 0, st, partial, nblk, rows_per_blk, M, C, Cs, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cs >> 2), dim3(256), 0, st, partial, nblk, rows_per_blk, M, C, Cs, eps,
                      momentum, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta,
                      coef_a, coef_c);
   return vmtl_check_launch();
@@ -459,24 +498,45 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, float invM, int training,
                                                               float* coef_a, float* coef_b, float* coef_c) {
-  __shared__ double sh[4];
-  const int c = blockIdx.x;  // sum outputs: exactly C entries (they may be slots of a flat gradient arena)
-  if (c >= C) {
-    if (threadIdx.x == 0 && coef_a != nullptr) coef_a[c] = coef_b[c] = coef_c[c] = 0.f;
+  // one workgroup per channel quad, one pass, one barrier pair (see bn_finalize_kernel); sum outputs: exactly C
+  // entries (they may be slots of a flat gradient arena)
+  __shared__ double sh[4][8];
+  const int c0 = blockIdx.x * 4, t = threadIdx.x;
+  const int c = c0 + t;
+  const bool fin = t < 4 && c < C;
+  float g = 1.f, is = 0.f, mu = 0.f;
+  if (fin && coef_a != nullptr) {
+    if (gamma != nullptr) g = gamma[c];
+    is = invstd[c];
+    mu = mean[c];
+  }
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int b = t; b < nblk; b += 256) {
+    const float* row = partial + (size_t)b * 2 * Cs + c0;
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(row);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(row + Cs);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[e] += (double)a4[e];
+      s[4 + e] += (double)b4[e];
+    }
+  }
+  block_sum_n<8>(s, sh);
+  if (t >= 4 || c >= Cs) return;
+  if (!fin) {
+    if (coef_a != nullptr) coef_a[c] = coef_b[c] = coef_c[c] = 0.f;
     return;
   }
-  const double s1 = block_rows_sum(partial, nblk, 2, 0, Cs, c, sh);
-  const double s2 = block_rows_sum(partial, nblk, 2, 1, Cs, c, sh);
-  if (threadIdx.x == 0) {
-    sum_dz[c] = (float)s1;
-    sum_dzx[c] = (float)s2;
-    if (coef_a != nullptr) {
-      const float gi = (gamma ? gamma[c] : 1.f) * invstd[c];
-      const float c1 = training ? (float)s1 * invM : 0.f, c2 = training ? (float)s2 * invM : 0.f;
-      coef_a[c] = gi;
-      coef_b[c] = -gi * invstd[c] * c2;
-      coef_c[c] = gi * (mean[c] * invstd[c] * c2 - c1);
-    }
+  const double s1 = s[t], s2 = s[4 + t];
+  sum_dz[c] = (float)s1;
+  sum_dzx[c] = (float)s2;
+  if (coef_a != nullptr) {
+    const float gi = g * is;
+    const float c1 = training ? (float)s1 * invM : 0.f, c2 = training ? (float)s2 * invM : 0.f;
+    coef_a[c] = gi;
+    coef_b[c] = -gi * is * c2;
+    coef_c[c] = gi * (mu * is * c2 - c1);
   }
 }
 
@@ -536,7 +596,7 @@ extern "C" int vmtl_bn_bwd(const float* x, const float* dy, const float* mean, c
     VMTL_ACT_SWITCH(act, CALL)
 #undef CALL
     if (need_sums)
-      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx,
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) >> 2), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx,
                          nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr, nullptr);
   }
   const int nb = sweep_blocks(M, Cs);
@@ -556,10 +616,11 @@ extern "C" int vmtl_bn_bwd_finalize(const float* partial, int nblk, int M, int C
                                     const float* mean, const float* invstd, const float* gamma, int training,
                                     float* coef_a, float* coef_b, float* coef_c, void* stream) {
   VMTL_ENTER();
-  if (!partial || nblk <= 0 || M <= 0 || C <= 0 || C > Cs || !sum_dz || !sum_dzx) return VMTL_ERR_ARG;
+  if (!partial || nblk <= 0 || M <= 0 || C <= 0 || C > Cs || (Cs & 3) || !sum_dz || !sum_dzx) return VMTL_ERR_ARG;
   const bool want = coef_a != nullptr;
   if (want && (!coef_b || !coef_c || !mean || !invstd)) return VMTL_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(want ? Cs : C), dim3(256), 0, (hipStream_t)stream, partial, nblk, C, Cs,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(want ? Cs >> 2 : (C + 3) >> 2), dim3(256), 0, (hipStream_t)stream, partial,
+                     nblk, C, Cs,
                      sum_dz, sum_dzx, mean, invstd, gamma, 1.f / (float)M, training, coef_a, coef_b, coef_c);
   return vmtl_check_launch();
 }

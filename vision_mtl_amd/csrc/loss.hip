@@ -33,29 +33,35 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 // per pixel when the logits are large, a systematic error the backward pass of a deep net amplifies.
 __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restrict__ z,
                                                             const long long* __restrict__ tgt,
-                                                            double* __restrict__ partial, int* __restrict__ err,
-                                                            long long P, int HW, int C, long long sb, long long sc,
-                                                            long long sp) {
+                                                            double* __restrict__ partial,
+                                                            long long* __restrict__ amax, long long P, int HW,
+                                                            int C, long long sb, long long sc, long long sp) {
   __shared__ double shd[4];
   double loss = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / HW, hw = i - b * HW;
     const float* r = z + b * sb + hw * sp;
     float m = r[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, r[c * sc]);
+    int am = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = r[c * sc];
+      if (v > m) { m = v; am = c; }  // first maximum wins, like torch.argmax on ties
+    }
+    if (amax != nullptr) amax[i] = am;
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(r[c * sc] - m);
     const long long t = tgt[i];
-    if (t < 0 || t >= C) atomicOr(err, 1);  // torch raises on an out-of-range class index
+    // torch raises on an out-of-range class index; raising here would need a host sync on the step path, so the
+    // pixel contributes NaN: the loss (and, in ce_bwd, the gradient) fails the step VISIBLY instead of silently
+    // adding 0 to a loss still divided by P
+    if (t < 0 || t >= C) loss += (double)__int_as_float(0x7fc00000);
     else loss += (double)(logf(s) - (r[t * sc] - m));
   }
   const double bs = block_sum_d(loss, shd);
   if (threadIdx.x == 0) partial[blockIdx.x] = bs;
 }
 
-// err (may be null): the loss becomes NaN when the flag is set - an out-of-range class index (torch raises on it;
-// raising here would need a host sync on the step path) then fails the step VISIBLY instead of silently
-// contributing 0 to a loss still divided by P.
+// err (may be null): the result becomes NaN when the flag is set.
 __global__ void sum_finalize_kernel(const double* __restrict__ partial, int n, double scale, float* out,
                                     const int* __restrict__ err) {
   __shared__ double shd[4];
@@ -121,6 +127,65 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_nhwc_kernel(const float* __
   }
 }
 
+// The same gradient when the NHWC rows are exactly the Q = ceil(C/4) quads (ld == 4*Q, the layout
+// ops._CrossEntropy.backward allocates): one thread per PIXEL - logits read once, coalesced along the pixel axis of
+// each channel plane, softmax evaluated once - and the wave's 64 finished rows (64*ld contiguous floats) turned
+// through LDS so every store instruction writes 1 KB of consecutive gradient.  138 -> ~60 us for 32x19x128x256 on
+// MI355X (the quad-per-thread form above re-reads the pixel's logits and re-evaluates 2*C expf in each of its Q threads).
+template <int Q>
+__global__ __launch_bounds__(256) void ce_bwd_nhwc_rows_kernel(const float* __restrict__ z,
+                                                               const long long* __restrict__ tgt,
+                                                               const float* __restrict__ gout, float* __restrict__ dz,
+                                                               long long P, int HW, int C, long long sb, long long sc,
+                                                               long long sp) {
+  __shared__ f32x4 sm[4][64 * Q];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float g = gout[0] / (float)P;
+  for (long long wg0 = (long long)blockIdx.x * 256; wg0 < P; wg0 += (long long)gridDim.x * 256) {  // uniform trip count
+    const long long base = wg0 + wave * 64, i = base + lane;
+    if (i < P) {
+      const long long b = i / HW, hw = i - b * HW;
+      const float* r = z + b * sb + hw * sp;
+      float v[4 * Q];
+#pragma unroll
+      for (int c = 0; c < 4 * Q; ++c) v[c] = c < C ? r[c * sc] : 0.f;
+      float m = v[0];
+#pragma unroll
+      for (int c = 1; c < 4 * Q; ++c) m = c < C ? fmaxf(m, v[c]) : m;
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4 * Q; ++c) {
+        v[c] = c < C ? expf(v[c] - m) : 0.f;
+        s += v[c];
+      }
+      const float inv = 1.f / s;
+      const long long t = tgt[i];
+      const float bad = (t < 0 || t >= C) ? __int_as_float(0x7fc00000) : 0.f;  // as the forward: NaN, never a silent 0
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * q + e;
+          o[e] = c < C ? (v[c] * inv - (c == t ? 1.f : 0.f)) * g + bad : 0.f;
+        }
+        sm[wave][lane * Q + q] = o;
+      }
+    }
+    __syncthreads();
+    if (base < P) {
+      const int nf4 = (int)(P - base < 64 ? P - base : 64) * Q;
+      f32x4* out = reinterpret_cast<f32x4*>(dz + base * (4 * Q));
+#pragma unroll
+      for (int j = 0; j < Q; ++j) {
+        const int idx = j * 64 + lane;
+        if (idx < nf4) out[idx] = sm[wave][idx];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static inline int ce_blocks(long long P) {
   long long nb = cdivll(P, CE_THREADS);
   if (nb > 2048) nb = 2048;
@@ -130,22 +195,37 @@ static inline int ce_blocks(long long P) {
 
 extern "C" long long vmtl_ce_workspace_bytes(long long P) { return ((long long)ce_blocks(P) + 1) * (long long)sizeof(double); }
 
-// workspace: vmtl_ce_workspace_bytes(P) bytes, 8-byte aligned; the last slot holds the int error flag
-// (non-zero after the call = some target outside [0, C)).
-extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void* workspace, int B, int HW,
-                           int C, long long sb, long long sc, long long sp, void* stream) {
-  VMTL_ENTER();
+// workspace: vmtl_ce_workspace_bytes(P) bytes, 8-byte aligned (per-block partial sums).  A target outside [0, C)
+// makes the loss NaN.
+static int ce_fwd_impl(const float* logits, const long long* target, float* loss, void* workspace, long long* amax,
+                       int B, int HW, int C, long long sb, long long sc, long long sp, void* stream) {
   if (!logits || !target || !loss || !workspace || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long P = (long long)B * HW;
   const int nblk = ce_blocks(P);
   double* partial = (double*)workspace;
-  int* err = (int*)(partial + nblk);
-  if (hipMemsetAsync(err, 0, sizeof(double), st) != hipSuccess) return VMTL_ERR_LAUNCH;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, err, P, HW, C,
-                     sb, sc, sp);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss, err);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, amax, P, HW, C, sb,
+                     sc, sp);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss,
+                     (const int*)nullptr);
   return vmtl_check_launch();
+}
+
+extern "C" int vmtl_ce_fwd(const float* logits, const long long* target, float* loss, void* workspace, int B, int HW,
+                           int C, long long sb, long long sc, long long sp, void* stream) {
+  VMTL_ENTER();
+  return ce_fwd_impl(logits, target, loss, workspace, nullptr, B, HW, C, sb, sc, sp, stream);
+}
+
+// vmtl_ce_fwd that also emits argmax_c logits (= the segmentation prediction of lit_module.py:137-138): the loss
+// pass finds every pixel's maximum anyway, so the prediction costs one 8-byte store instead of a second sweep
+// over the logits in its own launch
+extern "C" int vmtl_ce_fwd_argmax(const float* logits, const long long* target, float* loss, void* workspace,
+                                  long long* argmax, int B, int HW, int C, long long sb, long long sc, long long sp,
+                                  void* stream) {
+  VMTL_ENTER();
+  if (!argmax) return VMTL_ERR_ARG;
+  return ce_fwd_impl(logits, target, loss, workspace, argmax, B, HW, C, sb, sc, sp, stream);
 }
 
 extern "C" int vmtl_ce_bwd(const float* logits, const long long* target, const float* grad_out, float* dlogits, int B,
@@ -167,6 +247,25 @@ extern "C" int vmtl_ce_bwd_strided(const float* logits, const long long* target,
   VMTL_ENTER();
   if (!logits || !target || !grad_out || !dlogits || B <= 0 || HW <= 0 || C <= 0) return VMTL_ERR_ARG;
   const long long P = (long long)B * HW;
+  if (dsc == 1 && dsp == ((C + 3) & ~3) && dsp <= 32 && dsb == dsp * HW) {
+    long long nb = cdivll(P, 256);
+    if (nb > 8192) nb = 8192;
+#define CALL(QV)                                                                                                  \
+  hipLaunchKernelGGL((ce_bwd_nhwc_rows_kernel<QV>), dim3((int)nb), dim3(256), 0, (hipStream_t)stream, logits, target, \
+                     grad_out, dlogits, P, HW, C, sb, sc, sp)
+    switch ((int)dsp >> 2) {
+      case 1: CALL(1); break;
+      case 2: CALL(2); break;
+      case 3: CALL(3); break;
+      case 4: CALL(4); break;
+      case 5: CALL(5); break;
+      case 6: CALL(6); break;
+      case 7: CALL(7); break;
+      default: CALL(8); break;
+    }
+#undef CALL
+    return vmtl_check_launch();
+  }
   if (dsc == 1 && (dsp & 3) == 0 && dsp >= ((C + 3) & ~3) && dsb == dsp * HW) {
     long long nb = cdivll(P * ((C + 3) >> 2), CE_THREADS);
     if (nb > 8192) nb = 8192;

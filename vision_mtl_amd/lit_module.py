@@ -49,7 +49,8 @@ class MTLModule(nn.Module):
     def shared_step(self, batch: dict, stage: str) -> torch.Tensor:
         img, gt_mask, gt_depth = batch["img"], batch["mask"], batch["depth"]
         raw_out = self(img)
-        out = self.postprocess_raw_out(raw_out)
+        # the segmentation prediction comes out of the cross-entropy pass (calc_losses) when the criterion can emit it
+        out = self.postprocess_raw_out(raw_out, defer_segm_predictions=hasattr(self.segm_criterion, "forward_with_predictions"))
         all_losses = self.calc_losses(gt_mask, gt_depth, out)
         all_metrics = self.calc_metrics(gt_mask, gt_depth, out)
         self.update_step_stats(stage, all_losses, all_metrics)
@@ -74,7 +75,10 @@ class MTLModule(nn.Module):
                 "mae": self.metrics["mae"](out["depth_predictions"].detach(), gt_depth)}
 
     def calc_losses(self, gt_mask, gt_depth, out: dict) -> dict:  # reference lit_module.py:120-131
-        loss_segm = self.segm_criterion(out["segm_logits"], gt_mask)
+        if out.get("segm_predictions") is None and hasattr(self.segm_criterion, "forward_with_predictions"):
+            loss_segm, out["segm_predictions"] = self.segm_criterion.forward_with_predictions(out["segm_logits"], gt_mask)
+        else:
+            loss_segm = self.segm_criterion(out["segm_logits"], gt_mask)
         loss_depth = self.depth_criterion(out["depth_predictions"], gt_depth)
         if self.loss_segm_weight == 1.0 and self.loss_depth_weight == 1.0:
             loss = loss_segm + loss_depth
@@ -82,10 +86,11 @@ class MTLModule(nn.Module):
             loss = self.loss_segm_weight * loss_segm + self.loss_depth_weight * loss_depth
         return {"loss": loss, "loss_segm": loss_segm, "loss_depth": loss_depth}
 
-    def postprocess_raw_out(self, out: dict) -> dict:  # reference lit_module.py:133-144
+    def postprocess_raw_out(self, out: dict, defer_segm_predictions: bool = False) -> dict:  # reference lit_module.py:133-144
         segm_logits, depth_logits = out["segm"], out["depth"]
         return {"segm_logits": segm_logits,
-                "segm_predictions": ops.argmax_channels(segm_logits),  # argmax(softmax(z)) == argmax(z)
+                # argmax(softmax(z)) == argmax(z); deferred: calc_losses fills it from the cross-entropy pass
+                "segm_predictions": None if defer_segm_predictions else ops.argmax_channels(segm_logits),
                 "depth_predictions": ops.sigmoid(depth_logits).permute(0, 2, 3, 1)}
 
     def training_step(self, batch: dict, batch_idx: Any = 0):

@@ -50,9 +50,25 @@ def _k(name, _flop=None, _xflop=None, **kw):
         # _flop: algorithmic FLOPs of the reference formulation (logical channels); _xflop: FLOPs the launch
         # really executes when an algebraic rewrite makes them differ (up2_conv)
         _RECORD.append((name, dict(kw), float(_flop), float(_flop if _xflop is None else _xflop)))
+    if (_SKIP_SIDE_WORK and side.in_branch) or name in _SKIP_NAMES:
+        return
     lib().callk(name, stream=_stream(), **kw)
+    if _EXTRA_LAUNCHES and name in ("vmtl_bn_stats", "vmtl_bn_stats_coef"):
+        global _EXTRA_BUF
+        if _EXTRA_BUF is None:
+            _EXTRA_BUF = torch.zeros(64, device="cuda")
+        for _ in range(_EXTRA_LAUNCHES):
+            lib().callk("vmtl_fill_zero", p=_EXTRA_BUF, n=4, stream=_stream())
 
 
+# tuning aid: VMTL_DBG_EXTRA=n queues n more (trivial) launches behind every BatchNorm finalize: the marginal cost of a
+# launch on the dependent chain of the forward pass
+_EXTRA_LAUNCHES = int(os.environ.get("VMTL_DBG_EXTRA", "0"))
+_EXTRA_BUF = None
+# tuning aid: VMTL_DBG_SKIP_SIDE=1 drops every launch of the side branch (WRONG gradients; measures the main chain alone)
+_SKIP_SIDE_WORK = os.environ.get("VMTL_DBG_SKIP_SIDE", "0") == "1"
+# VMTL_DBG_SKIP=entry,entry: drop those launches (WRONG results; upper bound of what removing them would gain)
+_SKIP_NAMES = frozenset(n for n in os.environ.get("VMTL_DBG_SKIP", "").split(",") if n)
 _STAMPS = None  # bench.py (VMTL_STAMPS=1) sets this to a list to collect a two-stream timeline
 
 
@@ -106,6 +122,7 @@ class _SideBranch:
         self.nstreams = max(1, int(os.environ.get("VMTL_SIDE_STREAMS", "1")))
         self.streams = {}
         self.pending = None  # side streams with un-joined work (dict: stream -> True)
+        self.in_branch = False
         self.rr = 0
         self.task_streams = {}  # device index -> stream that runs the second task network of CSNet
         # off by default: measured on MI355X csnet 128x256 bs32 22.4 ms/step without, 22.9 ms with (one more
@@ -171,7 +188,11 @@ class _SideBranch:
             torch.autograd.Variable._execution_engine.queue_callback(self.join)
         self.pending[s] = True
         with torch.cuda.stream(s):
-            yield
+            self.in_branch = True
+            try:
+                yield
+            finally:
+                self.in_branch = False
 
 
 side = _SideBranch()
@@ -1711,7 +1732,7 @@ class _CrossEntropy(torch.autograd.Function):
     """mean_{b,h,w} -log_softmax(logits)[target]; logits (B,C,H,W) NCHW-contiguous."""
 
     @staticmethod
-    def forward(ctx, logits, target):
+    def forward(ctx, logits, target, want_argmax=False):
         logits = _req(logits, "logits")
         if target.dtype != torch.int64:
             raise TypeError("cross_entropy: target must be int64 class indices")
@@ -1722,13 +1743,19 @@ class _CrossEntropy(torch.autograd.Function):
         P = B * H * W
         loss = _empty((), logits)
         ws = torch.empty((lib().raw("vmtl_ce_workspace_bytes")(P) // 8,), dtype=torch.float64, device=logits.device)
+        ctx.save_for_backward(logits, target)
+        if want_argmax:
+            pred = torch.empty((B, H, W), dtype=torch.int64, device=logits.device)
+            _k("vmtl_ce_fwd_argmax", logits=logits, target=target, loss=loss, workspace=ws, argmax=pred, B=B, HW=H * W,
+               C=C, sb=C * H * W, sc=H * W, sp=1)
+            ctx.mark_non_differentiable(pred)
+            return loss, pred
         _k("vmtl_ce_fwd", logits=logits, target=target, loss=loss, workspace=ws, B=B, HW=H * W, C=C,
            sb=C * H * W, sc=H * W, sp=1)
-        ctx.save_for_backward(logits, target)
         return loss
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gpred=None):
         logits, target = ctx.saved_tensors
         B, C, H, W = logits.shape
         g = _req(g, "grad_output")
@@ -1741,11 +1768,16 @@ class _CrossEntropy(torch.autograd.Function):
            sb=C * H * W, sc=H * W, sp=1, dsb=H * W * ld, dsc=1, dsp=ld)
         dl = st[..., :C].permute(0, 3, 1, 2)
         dl._vmtl_nhwc = st
-        return dl, None
+        return dl, None, None
 
 
 def cross_entropy(logits, target):
-    return _CrossEntropy.apply(logits, target)
+    return _CrossEntropy.apply(logits, target, False)
+
+
+def cross_entropy_with_argmax(logits, target):
+    """(loss, argmax over the class axis) from one pass over the logits (reference lit_module.py:123 + 137-138)."""
+    return _CrossEntropy.apply(logits, target, True)
 
 
 class _SILog(torch.autograd.Function):
