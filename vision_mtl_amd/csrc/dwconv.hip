@@ -50,13 +50,11 @@ template <int ACT>
 __global__ __launch_bounds__(RED_THREADS) void dwconv_bn_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ ca, const float* __restrict__ cc, const float* __restrict__ wp,
     float* __restrict__ y, float* __restrict__ a_out, float* __restrict__ partial, int H, int W, int Cs, int Ho, int Wo, int K,
-    int stride, int pad, int M) {
+    int stride, int pad, int M, int rows_per_blk) {
   __shared__ f32x4 red_mean[RED_THREADS];
   __shared__ f32x4 red_m2[RED_THREADS];
   __shared__ float red_n[RED_THREADS];
   const int CQ = Cs >> 2;
-  const int nblk = gridDim.x;
-  const int rows_per_blk = (M + nblk - 1) / nblk;
   const int r_begin = blockIdx.x * rows_per_blk;
   const int r_end = min(M, r_begin + rows_per_blk);
   for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
@@ -117,6 +115,116 @@ __global__ __launch_bounds__(RED_THREADS) void dwconv_bn_fwd_kernel(
   }
 }
 
+// The same node for the shapes the encoder has (K in {3, 5}, stride in {1, 2}, even Wo), with everything the generic
+// kernel leaves to run time fixed at compile time: the K*K taps are unrolled, so the K+S loads of a tap row are in
+// flight together (the run-time tap loops issued one dependent L2 round trip per tap: 27 us for a 16x32x120 5x5
+// layer whose traffic is worth 8); the thread's K*K weight quads live in registers across its pixels; and a thread
+// produces TWO horizontally adjacent outputs per pass, which share K-S of their K columns - (K+S)/(2K) of the loads
+// and of the BatchNorm + activation evaluations (5x5 stride 1: 6 instead of 10 per tap row).
+template <int ACT, int K, int S, bool WLDS>
+__global__ __launch_bounds__(RED_THREADS) void dwconv_bn_fwd_pair_kernel(
+    const float* __restrict__ x, const float* __restrict__ ca, const float* __restrict__ cc, const float* __restrict__ wp,
+    float* __restrict__ y, float* __restrict__ a_out, float* __restrict__ partial, int H, int W, int Cs, int Ho, int Wo,
+    int M, int rows_per_blk) {
+  constexpr int PAD = (K - 1) / 2, NC = K + S;
+  // weights: 3x3 - the thread's 9 quads in registers; 5x5 (25 quads would cost 100 VGPRs) - the whole [K*K][Cs]
+  // matrix in LDS when a workgroup has enough pixels to pay for the copy (WLDS), else read through L1 as needed
+  constexpr bool WREG = K == 3;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // WLDS: [K*K][Cs]
+  if (WLDS) {
+    for (int i = threadIdx.x; i < K * K * (Cs >> 2); i += RED_THREADS)
+      reinterpret_cast<f32x4*>(wsm)[i] = reinterpret_cast<const f32x4*>(wp)[i];
+    __syncthreads();
+  }
+  __shared__ f32x4 red_mean[RED_THREADS];
+  __shared__ f32x4 red_m2[RED_THREADS];
+  __shared__ float red_n[RED_THREADS];
+  const int CQ = Cs >> 2;
+  const int r_begin = blockIdx.x * rows_per_blk;  // even (host)
+  const int r_end = min(M, r_begin + rows_per_blk);
+  for (int q0 = 0; q0 < CQ; q0 += RED_THREADS) {
+    const int cq = min(CQ - q0, RED_THREADS);
+    const int rpt = RED_THREADS / cq;
+    const int T = rpt * cq;
+    const int t = threadIdx.x;
+    const int q = q0 + t % cq, ro = t / cq;
+    f32x4 K0 = {0.f, 0.f, 0.f, 0.f}, s1 = K0, s2 = K0;
+    float n = 0.f;
+    if (t < T) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(ca + (size_t)q * 4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(cc + (size_t)q * 4);
+      f32x4 wgt[WREG ? K * K : 1];
+      if (WREG) {
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) wgt[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)i * Cs + (size_t)q * 4);
+      }
+      auto wq = [&](int tap) -> f32x4 {
+        if constexpr (WREG) return wgt[tap];
+        return *reinterpret_cast<const f32x4*>((WLDS ? wsm : wp) + tap * Cs + q * 4);
+      };
+      const float* xq = x + (size_t)q * 4;
+      for (int r = r_begin + 2 * ro; r < r_end; r += 2 * rpt) {  // outputs r, r + 1: the same row (Wo is even)
+        const int wo = r % Wo, ho = (r / Wo) % Ho, b = r / (Wo * Ho);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        // 5x5: the tap ROWS stay a loop (unrolled, the compiler hoists all 35 loads of a pixel pair: 256 VGPRs, one
+        // wave per SIMD; one row's K+S loads in flight per wave and 4 waves hide the latency better)
+#pragma unroll K > 3 ? 1 : K
+        for (int dh = 0; dh < K; ++dh) {
+          const int h = ho * S - PAD + dh;
+          const bool hok = (unsigned)h < (unsigned)H;
+          const int rowoff = (b * H + (hok ? h : 0)) * W;
+          f32x4 v[NC];
+          bool ok[NC];
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const int w = wo * S - PAD + j;
+            ok[j] = hok && (unsigned)w < (unsigned)W;
+            v[j] = *reinterpret_cast<const f32x4*>(xq + (size_t)(rowoff + (ok[j] ? w : 0)) * Cs);
+          }
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            f32x4 a = v[j] * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = ok[j] ? act_fwd(a[e], ACT) : 0.f;  // the conv pads the ACTIVATED map
+            if (j < K) acc0 += a * wq(dh * K + j);
+            if (j >= S) acc1 += a * wq(dh * K + j - S);
+            // input pixel (h, w) belongs to output (h / S, w / S): rows dh - PAD in [0, S), columns j - PAD in [0, 2S)
+            if (dh >= PAD && dh < PAD + S && j >= PAD && j < PAD + 2 * S) {
+              if (a_out != nullptr && ok[j])
+                *reinterpret_cast<f32x4*>(a_out + (size_t)(rowoff + wo * S - PAD + j) * Cs + (size_t)q * 4) = a;
+            }
+          }
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)r * Cs + (size_t)q * 4) = acc0;
+        *reinterpret_cast<f32x4*>(y + (size_t)(r + 1) * Cs + (size_t)q * 4) = acc1;
+        if (n == 0.f) K0 = acc0;  // shifted sums around the first value: accurate when |mean| >> std
+        const f32x4 d0 = acc0 - K0, d1 = acc1 - K0;
+        s1 += d0 + d1;
+        s2 += d0 * d0 + d1 * d1;
+        n += 2.f;
+      }
+    }
+    if (partial == nullptr) continue;
+    f32x4 mean = K0, m2 = {0.f, 0.f, 0.f, 0.f};
+    if (n > 0.f) {
+      mean = K0 + s1 * (1.f / n);
+      m2 = s2 - s1 * s1 * (1.f / n);
+    }
+    __syncthreads();
+    red_mean[t] = mean;
+    red_m2[t] = m2;
+    red_n[t] = t < T ? n : 0.f;
+    __syncthreads();
+    if (t < cq) {
+      float nt = red_n[t];
+      f32x4 mt = red_mean[t], m2t = red_m2[t];
+      for (int j = 1; j < rpt; ++j) chan_merge(nt, mt, m2t, red_n[t + j * cq], red_mean[t + j * cq], red_m2[t + j * cq]);
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * Cs + (size_t)(q0 + t) * 4) = mt;
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * Cs + (size_t)(q0 + t) * 4) = m2t;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __restrict__ dy,
                                                               const float* __restrict__ wp, float* __restrict__ dx,
                                                               int B, int H, int W, int Cs, int Ho, int Wo, int K,
@@ -144,6 +252,91 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
       }
     }
     reinterpret_cast<f32x4*>(dx)[i] = acc;
+  }
+}
+
+// The data gradient for the encoder's shapes (K in {3, 5}, stride in {1, 2}, even H and W) with the tap loops
+// resolved at compile time.  Stride 1: a thread produces two horizontally adjacent pixels from K rows of K+1 shared
+// dy columns.  Stride 2: a thread produces a 2x2 block of dx; which taps reach a pixel depends only on its parity, so
+// the block needs the (K+1)/2 x (K+1)/2 dy pixels around it once (4 loads for 3x3, 9 for 5x5, instead of a
+// run-time loop over K*K taps with a divisibility test per tap and pixel).
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_tpl_kernel(const float* __restrict__ dy,
+                                                                  const float* __restrict__ wp, float* __restrict__ dx,
+                                                                  int B, int H, int W, int Cs, int Ho, int Wo,
+                                                                  long long total) {
+  constexpr int PAD = (K - 1) / 2;
+  const int CQ = Cs >> 2;
+  const int H2 = S == 2 ? H >> 1 : H, W2 = W >> 1;  // thread grid: stride 1 -> (H, W/2) pairs, stride 2 -> 2x2 blocks
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % CQ);
+    const long long pix = idx / CQ;
+    const int j = (int)(pix % W2), i = (int)((pix / W2) % H2), b = (int)(pix / ((long long)W2 * H2));
+    const float* dyq = dy + (size_t)q * 4;
+    const float* wq = wp + (size_t)q * 4;
+    if constexpr (S == 1) {
+      const int h = i, w = 2 * j;
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int dh = 0; dh < K; ++dh) {
+        const int hn = h + PAD - dh;
+        const bool hok = (unsigned)hn < (unsigned)Ho;
+        const int rowoff = (b * Ho + (hok ? hn : 0)) * Wo;
+        f32x4 g[K + 1];
+#pragma unroll
+        for (int c = 0; c <= K; ++c) {
+          const int wn = w - PAD + c;
+          const bool ok = hok && (unsigned)wn < (unsigned)Wo;
+          g[c] = *reinterpret_cast<const f32x4*>(dyq + (size_t)(rowoff + (ok ? wn : 0)) * Cs);
+          if (!ok) g[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int c = 0; c <= K; ++c) {
+          // pixel w reads column wn = w + PAD - dw: dw = K - 1 - c; pixel w + 1: dw = K - c
+          if (c < K) a0 += g[c] * *reinterpret_cast<const f32x4*>(wq + (size_t)(dh * K + K - 1 - c) * Cs);
+          if (c >= 1) a1 += g[c] * *reinterpret_cast<const f32x4*>(wq + (size_t)(dh * K + K - c) * Cs);
+        }
+      }
+      float* o = dx + ((size_t)(b * H + h) * W + w) * Cs + (size_t)q * 4;
+      *reinterpret_cast<f32x4*>(o) = a0;
+      *reinterpret_cast<f32x4*>(o + Cs) = a1;
+    } else {
+      // pixel row h = 2i + ph takes tap dh iff ph + PAD - dh is even, from dy row i + (ph + PAD - dh) / 2
+      constexpr int OMIN = -((K - 1 - PAD) / 2), OMAX = (1 + PAD) / 2, NO = OMAX - OMIN + 1;
+      f32x4 g[NO][NO];
+#pragma unroll
+      for (int r = 0; r < NO; ++r) {
+        const int ho = i + OMIN + r;
+        const bool hok = (unsigned)ho < (unsigned)Ho;
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          const int wo = j + OMIN + c;
+          const bool ok = hok && (unsigned)wo < (unsigned)Wo;
+          g[r][c] = *reinterpret_cast<const f32x4*>(dyq + (size_t)((b * Ho + (hok ? ho : 0)) * Wo + (ok ? wo : 0)) * Cs);
+          if (!ok) g[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int dh = 0; dh < K; ++dh) {
+            if ((ph + PAD - dh) & 1) continue;
+            const int r = (ph + PAD - dh) / 2 - OMIN;  // (ph + PAD - dh) is even here: exact for negatives too
+#pragma unroll
+            for (int dw = 0; dw < K; ++dw) {
+              if ((pw + PAD - dw) & 1) continue;
+              const int c = (pw + PAD - dw) / 2 - OMIN;
+              acc += g[r][c] * *reinterpret_cast<const f32x4*>(wq + (size_t)(dh * K + dw) * Cs);
+            }
+          }
+          *reinterpret_cast<f32x4*>(dx + ((size_t)(b * H + 2 * i + ph) * W + 2 * j + pw) * Cs + (size_t)q * 4) = acc;
+        }
+      }
+    }
   }
 }
 
@@ -263,7 +456,7 @@ extern "C" int vmtl_dwconv_fwd(const float* x, const float* wp, float* y, int B,
 // rows_per_blk / (256 / quads) output pixels x K*K taps serially, so - unlike the pure reductions, which use
 // red_blocks() - the row blocks must stay SHORT for the deep layers (M = 1024 pixels x 240 quads left 64 workgroups
 // of 16 serial pixels each: slower than the three launches it replaces): two pixels per thread, at most 1024 rows.
-static int dwbn_blocks(int M, int Cs) {
+static int dwbn_rows(int M, int Cs) {
   const int cq = Cs >> 2;
   const int rpt = cq >= RED_THREADS ? 1 : RED_THREADS / cq;
   static int per_thread = -1;
@@ -274,10 +467,10 @@ static int dwbn_blocks(int M, int Cs) {
   }
   int rows = per_thread * rpt;
   if (rows < cdiv(M, 1024)) rows = cdiv(M, 1024);
-  return cdiv(M, rows);
+  return (rows + 1) & ~1;  // even: the pair kernel's blocks start on an even output pixel
 }
-extern "C" int vmtl_dwconv_bn_stats_rows(int M, int Cs) { return dwbn_blocks(M, Cs); }
-extern "C" int vmtl_dwconv_bn_stats_block(int M, int Cs) { return cdiv(M, dwbn_blocks(M, Cs)); }
+extern "C" int vmtl_dwconv_bn_stats_rows(int M, int Cs) { return cdiv(M, dwbn_rows(M, Cs)); }
+extern "C" int vmtl_dwconv_bn_stats_block(int M, int Cs) { return dwbn_rows(M, Cs); }
 
 extern "C" int vmtl_dwconv_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act, const float* wp,
                                   float* y, float* a_out, float* partial, int B, int H, int W, int Cs, int Ho, int Wo, int K,
@@ -287,10 +480,37 @@ extern "C" int vmtl_dwconv_bn_fwd(const float* x, const float* coef_a, const flo
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   if (pad != (K - 1) / 2) return VMTL_ERR_ARG;  // the a_out ownership rule assumes "same"-style padding
   const int M = B * Ho * Wo;
-  const int nblk = dwbn_blocks(M, Cs);
+  const int rows = dwbn_rows(M, Cs);
+  const int nblk = cdiv(M, rows);
+  static const bool generic_only = getenv("VMTL_DWBN_GENERIC") != nullptr;  // tuning aid: the run-time-K kernel
+  if (!generic_only && (Wo & 1) == 0 && (K == 3 || K == 5) && (stride == 1 || stride == 2) &&
+      (act == VMTL_ACT_NONE || act == VMTL_ACT_RELU || act == VMTL_ACT_HSWISH)) {
+    // 5x5 weights through LDS when the workgroup's pixels (rows x its share of the channel quads) outnumber the
+    // K*K*Cs floats it would copy
+    const bool wlds = K == 5 && rows >= 12;
+#define CALLP(A, KV, SV, WL)                                                                                           \
+  hipLaunchKernelGGL((dwconv_bn_fwd_pair_kernel<A, KV, SV, WL>), dim3(nblk), dim3(RED_THREADS),                        \
+                     WL ? (size_t)KV * KV * Cs * sizeof(float) : 0, (hipStream_t)stream, x, coef_a, coef_c, wp, y,     \
+                     a_out, partial, H, W, Cs, Ho, Wo, M, rows)
+#define CALLKS(A)                                              \
+  do {                                                         \
+    if (K == 3 && stride == 1) CALLP(A, 3, 1, false);          \
+    else if (K == 3) CALLP(A, 3, 2, false);                    \
+    else if (stride == 1 && wlds) CALLP(A, 5, 1, true);        \
+    else if (stride == 1) CALLP(A, 5, 1, false);               \
+    else if (wlds) CALLP(A, 5, 2, true);                       \
+    else CALLP(A, 5, 2, false);                                \
+  } while (0)
+    if (act == VMTL_ACT_NONE) CALLKS(VMTL_ACT_NONE);
+    else if (act == VMTL_ACT_RELU) CALLKS(VMTL_ACT_RELU);
+    else CALLKS(VMTL_ACT_HSWISH);
+#undef CALLKS
+#undef CALLP
+    return vmtl_check_launch();
+  }
 #define CALL(A)                                                                                                       \
   hipLaunchKernelGGL((dwconv_bn_fwd_kernel<A>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream, x, coef_a, coef_c, \
-                     wp, y, a_out, partial, H, W, Cs, Ho, Wo, K, stride, pad, M)
+                     wp, y, a_out, partial, H, W, Cs, Ho, Wo, K, stride, pad, M, rows)
   switch (act) {
     case VMTL_ACT_NONE: CALL(VMTL_ACT_NONE); break;
     case VMTL_ACT_RELU: CALL(VMTL_ACT_RELU); break;
@@ -307,6 +527,20 @@ extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx,
   if (!dy || !wp || !dx) return VMTL_ERR_ARG;
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   const long long total4 = (long long)B * H * W * (Cs >> 2);
+  static const bool generic_only = getenv("VMTL_DWBN_GENERIC") != nullptr;  // tuning aid: the run-time-K kernel
+  if (!generic_only && pad == (K - 1) / 2 && (K == 3 || K == 5) && (W & 1) == 0 &&
+      (stride == 1 || (stride == 2 && (H & 1) == 0 && Ho == H / 2 && Wo == W / 2))) {
+    const long long total = stride == 1 ? total4 / 2 : total4 / 4;
+#define CALLD(KV, SV)                                                                                              \
+  hipLaunchKernelGGL((dwconv_bwd_data_tpl_kernel<KV, SV>), dim3(dw_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, \
+                     wp, dx, B, H, W, Cs, Ho, Wo, total)
+    if (K == 3 && stride == 1) CALLD(3, 1);
+    else if (K == 3) CALLD(3, 2);
+    else if (stride == 1) CALLD(5, 1);
+    else CALLD(5, 2);
+#undef CALLD
+    return vmtl_check_launch();
+  }
   hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(dw_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, wp, dx, B,
                      H, W, Cs, Ho, Wo, K, stride, pad, total4);
   return vmtl_check_launch();

@@ -272,22 +272,25 @@ class _PackCache:
             self.shared_bufs[key] = e
         return e[1]
 
-    def get_custom(self, weight, kind, shape, fn):
+    def get_custom(self, weight, kind, shape, fn, deps=()):
         """Operand built by its own kernel (fn(weight, dst) launches it): cached like get(); refresh() rebuilds
         all of them on the side stream at the start of a step, so inside the step this is a lookup (+ one
-        event wait on first use)."""
+        event wait on first use).  deps: further tensors fn reads (it may capture them; the entry lives as long as
+        `weight` does) - a change of any of them invalidates the entry like a change of `weight`."""
         key = (id(weight), kind)
         e = self.custom.get(key)
         if e is not None and e["wref"]() is not weight:
             e = None
-        if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
+        ver = (weight._version,) + tuple((d.data_ptr(), d._version) for d in deps)
+        if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == ver and e["epoch"] == self.epoch:
             self.join()
             return e["dst"]
         if e is None or e["ptr"] != weight.data_ptr():
-            e = {"dst": _empty(shape, weight), "fn": fn, "wref": weakref.ref(weight), "ptr": weight.data_ptr()}
+            e = {"dst": _empty(shape, weight), "wref": weakref.ref(weight), "ptr": weight.data_ptr()}
             self.custom[key] = e
+        e["fn"], e["deps"] = fn, tuple(weakref.ref(d) for d in deps)
         fn(weight, e["dst"])
-        e["version"], e["epoch"] = weight._version, self.epoch
+        e["version"], e["epoch"] = ver, self.epoch
         return e["dst"]
 
     def join(self):
@@ -367,8 +370,12 @@ class _PackCache:
                     w = e["wref"]()
                     if w is None:
                         continue
+                    deps = [d() for d in e.get("deps", ())]
+                    if any(d is None for d in deps):
+                        continue
                     e["fn"](w, e["dst"])
-                    e["version"], e["epoch"] = w._version, self.epoch
+                    e["version"] = (w._version,) + tuple((d.data_ptr(), d._version) for d in deps)
+                    e["epoch"] = self.epoch
                 if use_side:
                     ev = torch.cuda.Event()
                     ev.record()
@@ -1537,9 +1544,12 @@ class _DecoderTail(torch.autograd.Function):
         stamp("main tail heads")
         fork = side.mark()
         # heads' data gradient; epilogue = ReLU + BatchNorm-2 backward reduction (dz2 and its per-tile column sums)
-        wd = pack(wa, 1, C2, 9, Ca, ldyh, 0, 9, 1, C2 * 9, flip=1)
-        _k("vmtl_pack_weights_slice", src=wb, dst=wd.view(-1)[Ca:], R0=C2, T=9, C=Cb, group=ldyh, sr0=9, st=1, sc=C2 * 9,
-           flip=1)
+        def pack_heads_dgrad(w, dst, wb=wb):  # both heads' flipped weights as ONE dgrad operand [C2][9][ldyh]
+            pack(w, 1, C2, 9, Ca, ldyh, 0, 9, 1, C2 * 9, flip=1, out=dst)
+            _k("vmtl_pack_weights_slice", src=wb, dst=dst.view(-1)[Ca:], R0=C2, T=9, C=Cb, group=ldyh, sr0=9, st=1,
+               sc=C2 * 9, flip=1)
+
+        wd = packs.get_custom(wa, "heads_dgrad", (C2, 9 * ldyh), pack_heads_dgrad, deps=(wb,))
         dz2, part2 = _empty((B, H, W, ldy2), x1), _empty((tiles, 2, ldy2), x1)
         _small(dy, wd, dz2, B, H, W, ldyh, ldy2, C2, C2, 2.0 * M * C2 * 9 * N, stats=part2, ep_mode=2,
                ez=(x2, mean2, invstd2, g2, b2, ACT_RELU))
