@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_tpl_kernel(const float* _
 // QL = min(16, pow2 >= quads) so narrow maps (C = 16..72) still use every lane.  Each thread keeps its
 // K*K tap sums in registers over its rows; row lanes are folded with wave shuffles + one LDS pass and
 // every workgroup writes one partial row [row block][tap][Cs]; the finalize sums row blocks in fp64.
-#define DWW_MAX_RB 256
+#define DWW_MAX_RB 512
 
 template <int KK>
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ x,
@@ -398,28 +398,99 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   }
 }
 
+// The same partial sums for the encoder's shapes (K in {3, 5}, stride in {1, 2}, even Wo): taps unrolled at compile
+// time, and a thread takes TWO horizontally adjacent output pixels per pass, whose K+S input columns per tap row are
+// loaded once for both (2 dy + K*(K+S) x loads instead of 2 + 2*K*K).
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_w_pair_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy, int H, int W, int Cs,
+                                                                int Ho, int Wo, int M, int QL, int rows_per_blk,
+                                                                float* partial) {
+  constexpr int KK = K * K, PAD = (K - 1) / 2, NC = K + S;
+  __shared__ f32x4 red[4][KK][16];
+  const int CQ = Cs >> 2;
+  const int ql = threadIdx.x & (QL - 1);  // quad lane
+  const int rl = threadIdx.x / QL;        // row lane 0 .. 256/QL-1
+  const int RL = 256 / QL;
+  const int q = blockIdx.x * QL + ql;
+  const int r_begin = blockIdx.y * rows_per_blk;  // even (host)
+  const int r_end = min(M, r_begin + rows_per_blk);
+  f32x4 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (q < CQ) {
+    const float* xq = x + (size_t)q * 4;
+    for (int r = r_begin + 2 * rl; r < r_end; r += 2 * RL) {  // outputs r, r + 1: the same row (Wo is even)
+      const int wo = r % Wo, ho = (r / Wo) % Ho, b = r / (Wo * Ho);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + (size_t)r * Cs + (size_t)q * 4);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(dy + (size_t)(r + 1) * Cs + (size_t)q * 4);
+#pragma unroll
+      for (int dh = 0; dh < K; ++dh) {
+        const int h = ho * S - PAD + dh;
+        const bool hok = (unsigned)h < (unsigned)H;
+        const int rowoff = (b * H + (hok ? h : 0)) * W;
+        f32x4 v[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          const int w = wo * S - PAD + j;
+          const bool ok = hok && (unsigned)w < (unsigned)W;
+          v[j] = *reinterpret_cast<const f32x4*>(xq + (size_t)(rowoff + (ok ? w : 0)) * Cs);
+          if (!ok) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+          if (j < K) acc[dh * K + j] += g0 * v[j];
+          if (j >= S) acc[dh * K + j - S] += g1 * v[j];
+        }
+      }
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    f32x4 v = acc[t];
+    for (int o = QL; o < 64; o <<= 1) {  // fold the row lanes of this wave (lane bits >= log2(QL))
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], o, 64);
+    }
+    if ((int)(threadIdx.x & 63) < QL) red[wave][t][ql] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < KK * QL; idx += 256) {
+    const int t = idx / QL, l = idx - t * QL;
+    const int qq = blockIdx.x * QL + l;
+    if (qq < CQ) {
+      const f32x4 s = ((red[0][t][l] + red[1][t][l]) + red[2][t][l]) + red[3][t][l];
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * KK + t) * Cs + (size_t)qq * 4) = s;
+    }
+  }
+}
+
 // dw[c][tap] (torch layout (C,1,K,K)) = sum over partial rows, fp64, fixed order.  A workgroup owns 32 consecutive
 // (tap, channel) elements x 8 row groups: consecutive threads read consecutive channels of a partial row, each sums
 // every 8th row, LDS folds the 8 groups.  (One workgroup per element launched C*K*K = 24,000 workgroups of two
 // barriers for the 960-channel 5x5 layers; one thread per element left a 256-load serial chain: 32 us.)
+template <int EG>  // (tap, channel) elements per workgroup; 256 / EG row groups
 __global__ __launch_bounds__(256) void dwconv_bwd_w_finalize_kernel(const float* __restrict__ partial, int nblk,
                                                                     int KK, int C, int Cs, float* dw) {
-  __shared__ double sh[8][32];
-  const int e = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + e;
+  constexpr int RG = 256 / EG;
+  __shared__ double sh[RG][EG];
+  const int e = threadIdx.x % EG, rg = threadIdx.x / EG;
+  const int i = blockIdx.x * EG + e;
   double s = 0.0;
   int t = 0, c = 0;
   if (i < KK * C) {
     t = i / C;
     c = i - t * C;
-    for (int b = rg; b < nblk; b += 8) s += (double)partial[((size_t)b * KK + t) * Cs + c];
+#pragma unroll 4
+    for (int b = rg; b < nblk; b += RG) s += (double)partial[((size_t)b * KK + t) * Cs + c];
   }
   sh[rg][e] = s;
   __syncthreads();
   if (rg == 0 && i < KK * C) {
     double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += sh[k][e];
+    for (int k = 0; k < RG; ++k) tot += sh[k][e];
     dw[c * KK + t] = (float)tot;
   }
 }
@@ -546,7 +617,30 @@ extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx,
   return vmtl_check_launch();
 }
 
-// partial: at least 256 * K*K * Cs floats (vmtl_reduce_rows(M) * K*K * Cs always suffices).  dw: torch (C,1,K,K) layout.
+// row blocks of the weight gradient's first stage: ~2048 workgroups in total (the 64x128 maps ran 256 workgroups = one
+// wave per SIMD at 0.5 TB/s), at least two passes per row lane, at most DWW_MAX_RB partial rows for the finalize
+static void dww_geometry(int M, int Cs, int* QLo, int* panels_o, int* rows_o, int* nblk_o) {
+  const int CQ = Cs >> 2;
+  int QL = 16;
+  while (QL > 1 && (QL >> 1) >= CQ) QL >>= 1;  // smallest power of two >= CQ, at most 16
+  const int panels = cdiv(CQ, QL);
+  const int rows_per_pass = 2 * (256 / QL);  // two output pixels per row lane and pass
+  int nblk = cdiv(2048, panels);
+  if (nblk > cdiv(M, 2 * rows_per_pass)) nblk = cdiv(M, 2 * rows_per_pass);
+  if (nblk > DWW_MAX_RB) nblk = DWW_MAX_RB;
+  if (nblk < 1) nblk = 1;
+  int rows = cdiv(M, nblk);
+  rows = (rows + 1) & ~1;  // even: the pair kernel's blocks start on an even output pixel
+  *QLo = QL; *panels_o = panels; *rows_o = rows; *nblk_o = cdiv(M, rows);
+}
+
+extern "C" int vmtl_dwconv_bwd_weight_rows(int M, int Cs) {
+  int QL, panels, rows, nblk;
+  dww_geometry(M, Cs, &QL, &panels, &rows, &nblk);
+  return nblk;
+}
+
+// partial: vmtl_dwconv_bwd_weight_rows(B*Ho*Wo, Cs) * K*K * Cs floats.  dw: torch (C,1,K,K) layout.
 extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,
                                       int C, int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream) {
   VMTL_ENTER();
@@ -554,22 +648,31 @@ extern "C" int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* pa
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   hipStream_t st = (hipStream_t)stream;
   const int M = B * Ho * Wo;
-  const int CQ = Cs >> 2;
-  int QL = 16;
-  while (QL > 1 && (QL >> 1) >= CQ) QL >>= 1;  // smallest power of two >= CQ, at most 16
-  const int panels = cdiv(CQ, QL);
-  const int rows_per_pass = 256 / QL;
-  int nblk = cdiv(1024, panels);                                           // ~1024 workgroups in total
-  if (nblk > cdiv(M, 4 * rows_per_pass)) nblk = cdiv(M, 4 * rows_per_pass);  // >= 4 rows per row lane
-  if (nblk > DWW_MAX_RB) nblk = DWW_MAX_RB;
-  if (nblk < 1) nblk = 1;
-  if (K == 3)
+  int QL, panels, rows, nblk;
+  dww_geometry(M, Cs, &QL, &panels, &rows, &nblk);
+  static const bool generic_only = getenv("VMTL_DWBN_GENERIC") != nullptr;  // tuning aid: the run-time-K kernel
+  if (!generic_only && (Wo & 1) == 0 && pad == (K - 1) / 2 && (K == 3 || K == 5) && (stride == 1 || stride == 2)) {
+#define CALLW(KV, SV)                                                                                              \
+  hipLaunchKernelGGL((dwconv_bwd_w_pair_kernel<KV, SV>), dim3(panels, nblk), dim3(256), 0, st, x, dy, H, W, Cs, Ho, Wo, \
+                     M, QL, rows, partial)
+    if (K == 3 && stride == 1) CALLW(3, 1);
+    else if (K == 3) CALLW(3, 2);
+    else if (stride == 1) CALLW(5, 1);
+    else CALLW(5, 2);
+#undef CALLW
+  } else if (K == 3) {
     hipLaunchKernelGGL((dwconv_bwd_w_kernel<9>), dim3(panels, nblk), dim3(256), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
                        stride, pad, M, QL, partial);
-  else
+  } else {
     hipLaunchKernelGGL((dwconv_bwd_w_kernel<25>), dim3(panels, nblk), dim3(256), 0, st, x, dy, H, W, Cs, Ho, Wo, K,
                        stride, pad, M, QL, partial);
-  hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel, dim3(cdiv(C * K * K, 32)), dim3(256), 0, st, partial, nblk, K * K,
-                     C, Cs, dw);
+  }
+  // few elements (narrow early layers, which also have the most partial rows): more row groups per element
+  if (C * K * K >= 4096)
+    hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel<32>, dim3(cdiv(C * K * K, 32)), dim3(256), 0, st, partial, nblk,
+                       K * K, C, Cs, dw);
+  else
+    hipLaunchKernelGGL(dwconv_bwd_w_finalize_kernel<8>, dim3(cdiv(C * K * K, 8)), dim3(256), 0, st, partial, nblk,
+                       K * K, C, Cs, dw);
   return vmtl_check_launch();
 }

@@ -893,7 +893,7 @@ class _DwConv(torch.autograd.Function):
                pad=pad)
         if ctx.needs_input_grad[1]:
             with side.branch(ctx.slot is not None, B * Ho * Wo, fork, x, dy):
-                partial = _empty((256, K * K, Cs), x)
+                partial = _empty((lib().raw("vmtl_dwconv_bwd_weight_rows")(B * Ho * Wo, Cs), K * K, Cs), x)
                 dw = _empty(weight.shape, x) if ctx.slot is None else ctx.slot
                 _k("vmtl_dwconv_bwd_weight", x=x, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho,
                    Wo=Wo, K=K, stride=stride, pad=pad)
@@ -962,7 +962,7 @@ class _BNActDw(torch.autograd.Function):
            sum_dz=dbeta, sum_dzx=dgamma, dx=dx, M=M, C=C, Cs=Cs, act=act, training=1 if training else 0)
         dw = _empty(weight.shape, x) if sw is None else sw
         with side.branch(sw is not None, B * Ho * Wo, fork, a, dy):
-            partial = _empty((256, K * K, Cs), x)
+            partial = _empty((lib().raw("vmtl_dwconv_bwd_weight_rows")(B * Ho * Wo, Cs), K * K, Cs), x)
             _k("vmtl_dwconv_bwd_weight", x=a, dy=dy, partial=partial, dw=dw, B=B, H=H, W=W, C=C, Cs=Cs, Ho=Ho, Wo=Wo, K=K,
                stride=stride, pad=pad)
             stamp(f"side bndw C={C}")
