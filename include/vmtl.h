@@ -129,6 +129,9 @@ int vmtl_dwconv_bn_fwd(const float* x, const float* coef_a, const float* coef_c,
                        int pad, void* stream);
 int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
                          int Wo, int K, int stride, int pad, void* stream);
+/* dx = dwconv^T(dy) + addend (a second gradient of the same tensor, e.g. the residual branch of the block) */
+int vmtl_dwconv_bwd_data_add(const float* dy, const float* wp, const float* addend, float* dx, int B, int H, int W,
+                             int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream);
 /* partial: vmtl_dwconv_bwd_weight_rows(B*Ho*Wo, Cs) * K*K * Cs floats of scratch; dw in the torch (C,1,K,K) layout */
 int vmtl_dwconv_bwd_weight_rows(int M, int Cs);
 int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, float* dw, int B, int H, int W,

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(RED_THREADS) void dwconv_bn_fwd_pair_kernel(
 }
 
 __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __restrict__ dy,
-                                                              const float* __restrict__ wp, float* __restrict__ dx,
+                                                              const float* __restrict__ wp,
+                                                              const float* __restrict__ addend, float* __restrict__ dx,
                                                               int B, int H, int W, int Cs, int Ho, int Wo, int K,
                                                               int stride, int pad, long long total4) {
   const int CQ = Cs >> 2;
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
         acc += g * wv;
       }
     }
+    if (addend != nullptr) acc += reinterpret_cast<const f32x4*>(addend)[i];
     reinterpret_cast<f32x4*>(dx)[i] = acc;
   }
 }
@@ -262,9 +264,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
 // run-time loop over K*K taps with a divisibility test per tap and pixel).
 template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bwd_data_tpl_kernel(const float* __restrict__ dy,
-                                                                  const float* __restrict__ wp, float* __restrict__ dx,
-                                                                  int B, int H, int W, int Cs, int Ho, int Wo,
-                                                                  long long total) {
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ addend,
+                                                                  float* __restrict__ dx, int B, int H, int W, int Cs,
+                                                                  int Ho, int Wo, long long total) {
   constexpr int PAD = (K - 1) / 2;
   const int CQ = Cs >> 2;
   const int H2 = S == 2 ? H >> 1 : H, W2 = W >> 1;  // thread grid: stride 1 -> (H, W/2) pairs, stride 2 -> 2x2 blocks
@@ -298,9 +301,13 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_tpl_kernel(const float* _
           if (c >= 1) a1 += g[c] * *reinterpret_cast<const f32x4*>(wq + (size_t)(dh * K + K - c) * Cs);
         }
       }
-      float* o = dx + ((size_t)(b * H + h) * W + w) * Cs + (size_t)q * 4;
-      *reinterpret_cast<f32x4*>(o) = a0;
-      *reinterpret_cast<f32x4*>(o + Cs) = a1;
+      const size_t oo = ((size_t)(b * H + h) * W + w) * Cs + (size_t)q * 4;
+      if (addend != nullptr) {
+        a0 += *reinterpret_cast<const f32x4*>(addend + oo);
+        a1 += *reinterpret_cast<const f32x4*>(addend + oo + Cs);
+      }
+      *reinterpret_cast<f32x4*>(dx + oo) = a0;
+      *reinterpret_cast<f32x4*>(dx + oo + Cs) = a1;
     } else {
       // pixel row h = 2i + ph takes tap dh iff ph + PAD - dh is even, from dy row i + (ph + PAD - dh) / 2
       constexpr int OMIN = -((K - 1 - PAD) / 2), OMAX = (1 + PAD) / 2, NO = OMAX - OMIN + 1;
@@ -333,7 +340,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_tpl_kernel(const float* _
               acc += g[r][c] * *reinterpret_cast<const f32x4*>(wq + (size_t)(dh * K + dw) * Cs);
             }
           }
-          *reinterpret_cast<f32x4*>(dx + ((size_t)(b * H + 2 * i + ph) * W + 2 * j + pw) * Cs + (size_t)q * 4) = acc;
+          const size_t oo = ((size_t)(b * H + 2 * i + ph) * W + 2 * j + pw) * Cs + (size_t)q * 4;
+          if (addend != nullptr) acc += *reinterpret_cast<const f32x4*>(addend + oo);
+          *reinterpret_cast<f32x4*>(dx + oo) = acc;
         }
       }
     }
@@ -592,9 +601,10 @@ extern "C" int vmtl_dwconv_bn_fwd(const float* x, const float* coef_a, const flo
   return vmtl_check_launch();
 }
 
-extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
-                                    int Wo, int K, int stride, int pad, void* stream) {
-  VMTL_ENTER();
+// dx = dwconv^T(dy) [+ addend]: addend (nullable, dx's shape) is a second gradient of the same tensor - the residual
+// branch of a block whose input also feeds the depthwise conv - added on the way out instead of in its own pass
+static int dw_bwd_data_impl(const float* dy, const float* wp, const float* addend, float* dx, int B, int H, int W, int Cs,
+                            int Ho, int Wo, int K, int stride, int pad, void* stream) {
   if (!dy || !wp || !dx) return VMTL_ERR_ARG;
   if (int e = dw_check(B, H, W, Cs, Ho, Wo, K, stride, pad)) return e;
   const long long total4 = (long long)B * H * W * (Cs >> 2);
@@ -604,7 +614,7 @@ extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx,
     const long long total = stride == 1 ? total4 / 2 : total4 / 4;
 #define CALLD(KV, SV)                                                                                              \
   hipLaunchKernelGGL((dwconv_bwd_data_tpl_kernel<KV, SV>), dim3(dw_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, \
-                     wp, dx, B, H, W, Cs, Ho, Wo, total)
+                     wp, addend, dx, B, H, W, Cs, Ho, Wo, total)
     if (K == 3 && stride == 1) CALLD(3, 1);
     else if (K == 3) CALLD(3, 2);
     else if (stride == 1) CALLD(5, 1);
@@ -612,9 +622,22 @@ extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx,
 #undef CALLD
     return vmtl_check_launch();
   }
-  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(dw_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, wp, dx, B,
-                     H, W, Cs, Ho, Wo, K, stride, pad, total4);
+  hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(dw_grid(total4)), dim3(256), 0, (hipStream_t)stream, dy, wp, addend, dx,
+                     B, H, W, Cs, Ho, Wo, K, stride, pad, total4);
   return vmtl_check_launch();
+}
+
+extern "C" int vmtl_dwconv_bwd_data(const float* dy, const float* wp, float* dx, int B, int H, int W, int Cs, int Ho,
+                                    int Wo, int K, int stride, int pad, void* stream) {
+  VMTL_ENTER();
+  return dw_bwd_data_impl(dy, wp, nullptr, dx, B, H, W, Cs, Ho, Wo, K, stride, pad, stream);
+}
+
+extern "C" int vmtl_dwconv_bwd_data_add(const float* dy, const float* wp, const float* addend, float* dx, int B, int H,
+                                        int W, int Cs, int Ho, int Wo, int K, int stride, int pad, void* stream) {
+  VMTL_ENTER();
+  if (!addend) return VMTL_ERR_ARG;
+  return dw_bwd_data_impl(dy, wp, addend, dx, B, H, W, Cs, Ho, Wo, K, stride, pad, stream);
 }
 
 // row blocks of the weight gradient's first stage: ~2048 workgroups in total (the 64x128 maps ran 256 workgroups = one

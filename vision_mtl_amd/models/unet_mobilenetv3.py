@@ -102,6 +102,17 @@ class DepthwiseSeparableConv(nn.Module):
         y = L.conv_bn_act(x, self.conv_dw, self.bn1, self.bn1.act_code)
         return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=x if self.has_skip else None)
 
+    def run_pre(self, raw, stats, rpb, bn_in, act_in: int) -> L.Act:
+        """The block on a pre-activation input: raw = the producing conv's output (with its BatchNorm partial rows),
+        bn_in / act_in that conv's BatchNorm + activation.  They run while the depthwise taps load (ops.bn_act_dwconv),
+        whose epilogue also yields bn1's statistics; the activated input comes back for the residual branch."""
+        dw = self.conv_dw
+        raw1, st1, rpb1, a = L.ops.bn_act_dwconv(raw, stats, rpb, bn_in, dw.in_channels, act_in, dw.weight,
+                                                  L._pair(dw.stride), L._pair(dw.padding),
+                                                  want_stats=self.bn1.training, return_act=True)
+        y = L.bn_act(L.Act(raw1, dw.out_channels), self.bn1, self.bn1.act_code, stats=st1, stats_rpb=rpb1)
+        return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=L.Act(a, dw.in_channels) if self.has_skip else None)
+
 
 class InvertedResidual(nn.Module):
     def __init__(self, in_chs, out_chs, k, stride, exp, se, act):
@@ -197,11 +208,25 @@ class MobileNetV3Encoder(nn.Module):
     def run(self, x: L.Act) -> t.List[L.Act]:
         m = self.model
         feats = [x]
-        y = L.conv_bn_act(x, m.conv_stem, m.bn1, ACT_HSWISH)
+        first = m.blocks[0][0]
+        fuse_stem = (L.ops.FUSE_DW and isinstance(first, DepthwiseSeparableConv) and m.bn1.momentum is not None
+                     and first.conv_dw.kernel_size[0] in (3, 5) and os.environ.get("VMTL_FUSE_STEM", "1") != "0")
+        if fuse_stem:
+            # stem conv -> [stem BatchNorm + hardswish + the first block's depthwise conv as one pre-activation node]
+            train = m.bn1.training
+            out = L.ops.conv2d(x.t, m.conv_stem.weight, None, L._pair(m.conv_stem.stride), L._pair(m.conv_stem.padding),
+                               want_stats=train)
+            raw0, st0 = out if train else (out, None)
+            rpb0 = getattr(st0, "_vmtl_rpb", 0) if st0 is not None else 0
+            y = first.run_pre(raw0, st0, rpb0, m.bn1, ACT_HSWISH)
+        else:
+            y = L.conv_bn_act(x, m.conv_stem, m.bn1, ACT_HSWISH)
         groups = [[0], [1], [2], [3, 4], [5, 6]]
         for g in groups[: self._depth]:
             for si in g:
                 for blk in m.blocks[si]:
+                    if fuse_stem and blk is first:
+                        continue
                     y = blk.run(y)
             feats.append(y)
         return feats

@@ -912,7 +912,7 @@ class _BNActDw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, stats, rpb, gamma, beta, rm, rv, nbt, weight, cfg):
-        C, training, momentum, eps, act, stride, pad, want_stats = cfg
+        C, training, momentum, eps, act, stride, pad, want_stats, return_act = cfg
         x, weight = _req(x, "x"), _req(weight, "weight")
         B, H, W, Cs = x.shape
         Cw, one, K, K2 = weight.shape
@@ -923,7 +923,7 @@ class _BNActDw(torch.autograd.Function):
         mean, invstd, ca, cc = _bn_fwd_coef(x, stats, rpb, gamma, beta, rm, rv, nbt, C, training, momentum, eps)
         wp = packs.get(weight, "dw", (1, 1, K * K, C, Cs, 0, 0, 1, K * K, 0))
         need_bwd = any(ctx.needs_input_grad)
-        a = _empty(x.shape, x) if need_bwd else None
+        a = _empty(x.shape, x) if need_bwd or return_act else None
         y = _empty((B, Ho, Wo, Cs), x)
         ostats = None
         if want_stats:
@@ -936,14 +936,18 @@ class _BNActDw(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if ostats is not None:
             ctx.mark_non_differentiable(ostats)
+        if return_act:  # a = act(BN(x)) as a second differentiable output (the residual branch of the block reads it)
+            return y, ostats, a
         return y, ostats
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, dy, _dstats, d_a=None):
         x, a, weight, wp, mean, invstd, gamma, beta = ctx.saved_tensors
         C, training, act, stride, pad = ctx.cfg
         sg, sb, sw = ctx.slots
         if dy is None:
+            if d_a is not None:
+                raise NotImplementedError("bn_act_dwconv: gradient through the activation output only")
             return (None,) * 10
         dy = _req(dy, "dy")
         B, H, W, Cs = x.shape
@@ -953,7 +957,11 @@ class _BNActDw(torch.autograd.Function):
         stamp(f"main bndw M={B * Ho * Wo} C={C}")
         fork = side.mark()
         da = _empty(x.shape, x)
-        _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=da, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
+        if d_a is not None:  # + the gradient that reached a through its other consumer, added on the way out
+            _k("vmtl_dwconv_bwd_data_add", dy=dy, wp=wp, addend=_req(d_a, "d_a"), dx=da, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo,
+               K=K, stride=stride, pad=pad)
+        else:
+            _k("vmtl_dwconv_bwd_data", dy=dy, wp=wp, dx=da, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, K=K, stride=stride, pad=pad)
         dgamma = _empty((C,), x) if sg is None else sg
         dbeta = _empty((C,), x) if sb is None else sb
         dx = _empty(x.shape, x)
@@ -970,15 +978,17 @@ class _BNActDw(torch.autograd.Function):
         return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), None
 
 
-def bn_act_dwconv(x, stats, rpb, bn, C, act, weight, stride=1, pad=1, want_stats=True):
-    """(y_raw, stats, rows_per_block) = dwconv(act(bn(x_raw))); bn = the nn.BatchNorm2d container of x's layer."""
+def bn_act_dwconv(x, stats, rpb, bn, C, act, weight, stride=1, pad=1, want_stats=True, return_act=False):
+    """(y_raw, stats, rows_per_block[, a]) = dwconv(act(bn(x_raw))); bn = the nn.BatchNorm2d container of x's layer;
+    return_act: also hand back a = act(bn(x_raw)) (differentiable) for a second consumer of the activation."""
     if bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
-    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, stride, pad, bool(want_stats))
-    y, ostats = _BNActDw.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                               bn.num_batches_tracked, weight, cfg)
+    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, stride, pad, bool(want_stats), bool(return_act))
+    out = _BNActDw.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                         bn.num_batches_tracked, weight, cfg)
+    y, ostats = out[0], out[1]
     orpb = lib().raw("vmtl_dwconv_bn_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3]) if ostats is not None else 0
-    return y, ostats, orpb
+    return (y, ostats, orpb, out[2]) if return_act else (y, ostats, orpb)
 
 
 def dwconv(x, weight, stride=1, pad=1):
