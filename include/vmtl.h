@@ -235,6 +235,10 @@ int vmtl_channel_scale_add(const float* x, const float* s, const float* t, float
                            int Cs, void* stream);
 /* models/cross_stitch_model.py:32-37 (diagonal of the 2x2 stitch matrix) */
 int vmtl_stitch(const float* x, const float* w, float* y, long long M, int C, int Cs, int wstride, void* stream);
+/* its backward in one sweep: dx (nullable) = w * dy, dw[c] = sum_m x*dy (reduce_all: one scalar);
+ * partial: vmtl_reduce_rows(M) * Cs floats of scratch */
+int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, float* dx, float* partial, float* dw, int M,
+                    int C, int Cs, int wstride, int reduce_all, void* stream);
 /* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */
 int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream);
 int vmtl_fill_zero(float* p, long long n, void* stream); /* n floats <- 0 (a memset node) */

@@ -665,6 +665,43 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
   if (threadIdx.x == 0) out[c] = (float)s;
 }
 
+// cross-stitch backward in one sweep (reference models/cross_stitch_model.py:21-37): dx = w * dy and the partial
+// column sums of x * dy (the stitch weight's gradient) - dy is read once instead of by a scale pass and a reduction
+__global__ __launch_bounds__(RED_THREADS) void stitch_bwd_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 const float* __restrict__ w, float* __restrict__ dx,
+                                                                 int M, int C, int Cs, int wstride, float* partial) {
+  const int CQ = Cs >> 2;
+  column_reduce<1>(M, CQ, Cs, partial, [&](int r, int q, f32x4* acc) {
+    const size_t off = (size_t)r * Cs + (size_t)q * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + off);
+    acc[0] += g * *reinterpret_cast<const f32x4*>(x + off);
+    if (dx != nullptr) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = q * 4 + e;
+        v[e] = c < C ? g[e] * w[(size_t)c * wstride] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dx + off) = v;
+    }
+  });
+}
+
+// dx (nullable) = w[c * wstride] * dy;  dw[c] = sum_m x*dy  (reduce_all: one scalar, the layer-wise stitch weight).
+// partial: vmtl_reduce_rows(M) * Cs floats.
+extern "C" int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, float* dx, float* partial, float* dw,
+                               int M, int C, int Cs, int wstride, int reduce_all, void* stream) {
+  VMTL_ENTER();
+  if (!x || !dy || !w || !partial || !dw || M <= 0 || C <= 0 || C > Cs || (Cs & 3)) return VMTL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = red_blocks(M);
+  hipLaunchKernelGGL(stitch_bwd_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, w, dx, M, C, Cs, wstride, partial);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(reduce_all ? 1 : C), dim3(256), 0, st, partial, nblk, C, Cs,
+                     reduce_all, dw);
+  return vmtl_check_launch();
+}
+
 extern "C" int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
                            float* partial, float* out, void* stream) {
   VMTL_ENTER();

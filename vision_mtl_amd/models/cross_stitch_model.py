@@ -162,7 +162,9 @@ class CSNet(nn.Module):
     def forward(self, x: torch.Tensor) -> dict:
         if self._program is None:
             self._compile()
-        ops.packs.refresh()  # one batched weight-packing launch for the whole step
+        task_par = (x.is_cuda and ops.side.enabled and ops.side.task_parallel and self.num_tasks == 2
+                    and self.debug_acts is None)
+        ops.packs.refresh(task_mode=task_par)  # one batched weight-packing launch for the whole step
         x0 = L.from_nchw(x)
         feats = {task: x0 for task in self.model_names}
         skips = {task: [] for task in self.model_names}
@@ -170,8 +172,7 @@ class CSNet(nn.Module):
         # second one runs on its own stream - a parallel branch of the captured graph - and is joined at the end.
         main = torch.cuda.current_stream() if x.is_cuda else None
         streams = {task: None for task in self.model_names}
-        if (main is not None and ops.side.enabled and ops.side.task_parallel and self.num_tasks == 2
-                and self.debug_acts is None):
+        if task_par:
             s1 = ops.side.task_stream(x.device)
             s1.wait_stream(main)
             x0.t.record_stream(s1)

@@ -125,9 +125,12 @@ class _SideBranch:
         self.in_branch = False
         self.rr = 0
         self.task_streams = {}  # device index -> stream that runs the second task network of CSNet
-        # off by default: measured on MI355X csnet 128x256 bs32 22.4 ms/step without, 22.9 ms with (one more
-        # hardware queue in the replayed graph costs more than the overlap of the two launch-bound nets gains)
-        self.task_parallel = os.environ.get("VMTL_TASK_STREAMS", "0") != "0"
+        # CSNet's two task networks as two parallel graph branches.  Measured on MI355X (csnet 128x256 bs 32): 17.7 ms/step
+        # on one stream with the weight gradients on the side stream, 17.7 with task streams AND the side branch (three
+        # hardware queues), 15.4 with the task streams alone - so while a task-parallel model is stepping (task_mode,
+        # set by its forward through packs.refresh) the weight gradients stay on their task's stream
+        self.task_parallel = os.environ.get("VMTL_TASK_STREAMS", "1") != "0"
+        self.task_mode = False
 
     def task_stream(self, device):
         """Stream for the second of two independent task networks (CSNet: the cross-stitch layers of the
@@ -151,12 +154,19 @@ class _SideBranch:
 
     def join(self):
         pend, self.pending = self.pending, None
-        if pend:
+        if pend is not None:
             for s in pend:
                 torch.cuda.current_stream(s.device).wait_stream(s)
             for s in self.task_streams.values():
                 torch.cuda.current_stream(s.device).wait_stream(s)
         packs.join()
+
+    def join_at_end_of_backward(self):
+        """Called from a backward function: the stream that called backward() waits for the side / task streams
+        when the engine is done (gradients written into arena slots have no AccumulateGrad node it could sync on)."""
+        if self.pending is None:
+            self.pending = {}
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
 
     def mark(self):
         """Record the fork point on the current (main) stream.  Taken on entry of a backward function so the
@@ -174,7 +184,7 @@ class _SideBranch:
         """Run the enclosed launches on the side stream, ordered after `mark`.  `tensors` are main-stream
         tensors the launches read: the allocator must not recycle them for main-stream work until the
         side stream is past these launches."""
-        if not (self.enabled and use and mark is not None and rows <= self.max_rows):
+        if not (self.enabled and use and mark is not None and rows <= self.max_rows) or self.task_mode:
             yield
             return
         main = torch.cuda.current_stream()
@@ -183,9 +193,7 @@ class _SideBranch:
         for t in tensors:
             if t is not None:
                 t.record_stream(s)
-        if self.pending is None:
-            self.pending = {}
-            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        self.join_at_end_of_backward()
         self.pending[s] = True
         with torch.cuda.stream(s):
             self.in_branch = True
@@ -330,8 +338,10 @@ class _PackCache:
         self.table_side = table([e for e in live if e["side"]])
         self.dirty = False
 
-    def refresh(self):
-        """Re-pack every known weight (call once at the start of a step, before the forward)."""
+    def refresh(self, task_mode=False):
+        """Re-pack every known weight (call once at the start of a step, before the forward).  task_mode: the model
+        stepping runs its task networks on parallel streams (see _SideBranch.task_parallel)."""
+        side.task_mode = bool(task_mode)
         self.join()
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:
@@ -354,7 +364,9 @@ class _PackCache:
         # before the decoder, so they are built on the side stream while the encoder runs; get() / get_custom() make
         # the consuming stream wait for the event on first use
         if self.custom or self.table_side is not None:
-            use_side = side.enabled
+            # task_mode: both task streams consume packed operands, and only the first get() waits for the side
+            # stream's event - pack on the calling stream instead
+            use_side = side.enabled and not side.task_mode
             if use_side:
                 main = torch.cuda.current_stream()
                 s = side.stream(main.device)
@@ -1351,16 +1363,22 @@ class _Stitch(torch.autograd.Function):
         B, H, W, Cs = x.shape
         M = B * H * W
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = _empty(x.shape, x)
-            _k("vmtl_stitch", x=dy, w=weights.view(-1)[off:], y=dx, M=M, C=C, Cs=Cs, wstride=1 if channel_wise else 0)
+        wv = weights.view(-1)[off:]
+        ws = 1 if channel_wise else 0
         if ctx.needs_input_grad[1]:
             n = C if channel_wise else 1
             if ctx.slot is not None:  # arena slot (off-diagonal entries stay at their initial zero)
-                _colsum(x, dy, M, C, Cs, mode=1, reduce_all=0 if channel_wise else 1, out=ctx.slot.view(-1)[off:off + n])
+                out = ctx.slot.view(-1)[off:off + n]
             else:
                 dw = torch.zeros_like(weights)
-                _colsum(x, dy, M, C, Cs, mode=1, reduce_all=0 if channel_wise else 1, out=dw.view(-1)[off:off + n])
+                out = dw.view(-1)[off:off + n]
+            dx = _empty(x.shape, x) if ctx.needs_input_grad[0] else None
+            # one sweep: dx = w * dy and the column sums of x * dy
+            _k("vmtl_stitch_bwd", x=x, dy=dy, w=wv, dx=dx, partial=_empty((_reduce_rows(M), Cs), x), dw=out, M=M, C=C, Cs=Cs,
+               wstride=ws, reduce_all=0 if channel_wise else 1)
+        elif ctx.needs_input_grad[0]:
+            dx = _empty(x.shape, x)
+            _k("vmtl_stitch", x=dy, w=wv, y=dx, M=M, C=C, Cs=Cs, wstride=ws)
         return dx, dw, None, None
 
 
@@ -1427,6 +1445,8 @@ class _ToNCHW(torch.autograd.Function):
     def backward(ctx, dy):
         B, C, H, W = dy.shape
         ld = ctx.Cs
+        if side.task_mode:  # first backward node of a task network: its stream is joined when the engine is done
+            side.join_at_end_of_backward()
         if (dy.is_cuda and dy.dtype == torch.float32 and dy.stride() == (H * W * ld, 1, W * ld, ld) and dy.storage_offset() == 0
                 and dy.untyped_storage().nbytes() == 4 * B * H * W * ld and getattr(dy, "_vmtl_nhwc", None) is not None):
             # the cross-entropy backward already wrote this gradient as NHWC rows of exactly our width, pad lanes zero
