@@ -241,6 +241,8 @@ int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, float* dx, 
                     int C, int Cs, int wstride, int reduce_all, void* stream);
 /* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */
 int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream);
+/* y = wa*a + wb*b: the weighted sum of the task losses (lit_module.py:127-129) */
+int vmtl_axpby(const float* a, const float* b, float* y, float wa, float wb, long long total, void* stream);
 int vmtl_fill_zero(float* p, long long n, void* stream); /* n floats <- 0 (a memset node) */
 /* lit_module.py:137-138 (argmax of softmax == argmax of logits) */
 int vmtl_argmax_channels(const float* z, long long* out, int B, int HW, int C, long long sb, long long sc,

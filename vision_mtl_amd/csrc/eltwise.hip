@@ -440,6 +440,19 @@ __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, co
   }
 }
 
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ y, float wa, float wb, long long total) {
+  GRID_STRIDE(i, total) y[i] = wa * a[i] + wb * b[i];
+}
+
+// y = wa * a + wb * b (the weighted sum of the two task losses, reference lit_module.py:127-129)
+extern "C" int vmtl_axpby(const float* a, const float* b, float* y, float wa, float wb, long long total, void* stream) {
+  VMTL_ENTER();
+  if (!a || !b || !y || total <= 0) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, b, y, wa, wb, total);
+  return vmtl_check_launch();
+}
+
 extern "C" int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream) {
   VMTL_ENTER();
   if (!a || !y || total <= 0 || mode < 0 || mode > 3 || (mode != 1 && !b)) return VMTL_ERR_ARG;

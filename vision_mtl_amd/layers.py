@@ -37,6 +37,14 @@ def to_nchw(a: Act) -> torch.Tensor:
     return ops.to_nchw(a.t, a.C)
 
 
+def fork(a: Act):
+    """Two handles on an activation with two consumers; their gradients are summed by this library's kernel."""
+    if not a.t.requires_grad:
+        return a, a
+    t1, t2 = ops.fork(a.t)
+    return Act(t1, a.C), Act(t2, a.C)
+
+
 def _momentum(bn: nn.BatchNorm2d) -> float:
     if bn.momentum is None:
         # torch switches to a cumulative moving average (factor 1/num_batches_tracked), which needs the counter on

@@ -40,6 +40,7 @@ class MTLModule(nn.Module):
                         "jaccard_index": M.JaccardIndex(num_classes), "mae": M.MeanAbsoluteError()}
         self.automatic_optimization = False
         self.compute_metrics = True  # bench.py turns this off to time exactly fwd + losses + bwd
+        self._nan = {}  # device -> the NaN placeholder of the skipped metrics (built once, not filled every step)
         self.dp_arena = None  # a dp.FlatArena: training_step's loss then averages gradients over ranks at end of backward
 
     def forward(self, x: torch.Tensor) -> dict:
@@ -66,7 +67,9 @@ class MTLModule(nn.Module):
 
     def calc_metrics(self, gt_mask, gt_depth, out: dict) -> dict:
         if not self.compute_metrics:
-            nan = torch.full((), float("nan"), device=gt_mask.device)
+            nan = self._nan.get(gt_mask.device)
+            if nan is None:
+                nan = self._nan[gt_mask.device] = torch.full((), float("nan"), device=gt_mask.device)
             return {"accuracy": nan, "jaccard_index": nan, "fbeta_score": nan, "mae": nan}
         cm = M.confusion_matrix(out["segm_predictions"], gt_mask, self.num_classes)
         return {"accuracy": self.metrics["accuracy"].from_confusion(cm),
@@ -80,8 +83,8 @@ class MTLModule(nn.Module):
         else:
             loss_segm = self.segm_criterion(out["segm_logits"], gt_mask)
         loss_depth = self.depth_criterion(out["depth_predictions"], gt_depth)
-        if self.loss_segm_weight == 1.0 and self.loss_depth_weight == 1.0:
-            loss = loss_segm + loss_depth
+        if loss_segm.is_cuda and loss_segm.dim() == 0 and loss_depth.dim() == 0:
+            loss = ops.add_losses(loss_segm, loss_depth, self.loss_segm_weight, self.loss_depth_weight)
         else:
             loss = self.loss_segm_weight * loss_segm + self.loss_depth_weight * loss_depth
         return {"loss": loss, "loss_segm": loss_segm, "loss_depth": loss_depth}

@@ -162,8 +162,12 @@ class CSNet(nn.Module):
     def forward(self, x: torch.Tensor) -> dict:
         if self._program is None:
             self._compile()
+        # task streams only with a gradient arena (or no gradients at all): torch's AccumulateGrad nodes would otherwise
+        # run on a stream other than the one they were created on (extra syncs, a warning, trouble under capture)
         task_par = (x.is_cuda and ops.side.enabled and ops.side.task_parallel and self.num_tasks == 2
-                    and self.debug_acts is None)
+                    and self.debug_acts is None
+                    and (not torch.is_grad_enabled()
+                         or getattr(next(self.parameters()), "_vmtl_gslot", None) is not None))
         ops.packs.refresh(task_mode=task_par)  # one batched weight-packing launch for the whole step
         x0 = L.from_nchw(x)
         feats = {task: x0 for task in self.model_names}

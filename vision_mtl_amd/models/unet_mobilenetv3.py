@@ -99,8 +99,9 @@ class DepthwiseSeparableConv(nn.Module):
         self.drop_path = nn.Identity()
 
     def run(self, x: L.Act) -> L.Act:
+        x, res = L.fork(x) if self.has_skip else (x, None)
         y = L.conv_bn_act(x, self.conv_dw, self.bn1, self.bn1.act_code)
-        return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=x if self.has_skip else None)
+        return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=res)
 
     def run_pre(self, raw, stats, rpb, bn_in, act_in: int) -> L.Act:
         """The block on a pre-activation input: raw = the producing conv's output (with its BatchNorm partial rows),
@@ -130,6 +131,7 @@ class InvertedResidual(nn.Module):
 
     def run(self, x: L.Act) -> L.Act:
         ops = L.ops
+        x, res = L.fork(x) if self.has_skip else (x, None)
         if ops.FUSE_DW and self.bn1.act_code in (ACT_NONE, ACT_RELU, ACT_HSWISH):
             # conv_pw -> [bn1 + act + conv_dw as one pre-activation node, bn2's statistics from its epilogue] -> bn2 + act
             train = self.bn1.training
@@ -145,7 +147,7 @@ class InvertedResidual(nn.Module):
             y = L.conv_bn_act(y, self.conv_dw, self.bn2, self.bn2.act_code)
         if isinstance(self.se, SqueezeExcite):
             y = self.se.run(y)
-        return L.conv_bn_act(y, self.conv_pwl, self.bn3, ACT_NONE, res=x if self.has_skip else None)
+        return L.conv_bn_act(y, self.conv_pwl, self.bn3, ACT_NONE, res=res)
 
 
 class ConvBnAct(nn.Module):
@@ -228,7 +230,11 @@ class MobileNetV3Encoder(nn.Module):
                     if fuse_stem and blk is first:
                         continue
                     y = blk.run(y)
-            feats.append(y)
+            if g is not groups[self._depth - 1]:  # the feature goes to the decoder AND on to the next stage
+                y, tap = L.fork(y)
+                feats.append(tap)
+            else:
+                feats.append(y)
         return feats
 
 

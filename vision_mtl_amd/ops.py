@@ -1754,6 +1754,57 @@ def sigmoid(x):
     return _Sigmoid.apply(x)
 
 
+class _Fork(torch.autograd.Function):
+    """Two handles on one tensor for its two consumers (a block's residual branch and its first conv, an encoder
+    feature and the next stage).  Autograd would sum the two gradients with an ATen kernel; here the sum is a
+    launch of this library (vmtl_eltwise), so the step runs no kernel the C ABI does not export."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.detach(), x.detach()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        g1, g2 = _req(g1, "grad"), _req(g2, "grad")
+        out = _empty(g1.shape, g1)
+        _k("vmtl_eltwise", a=g1, b=g2, y=out, mode=0, total=g1.numel())
+        return out
+
+
+def fork(x):
+    return _Fork.apply(x)
+
+
+class _AddScalars(torch.autograd.Function):
+    """wa * a + wb * b for two scalar losses (reference lit_module.py:127-129) as one launch of this library."""
+
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        a, b = _req(a, "a"), _req(b, "b")
+        out = _empty(a.shape, a)
+        _k("vmtl_axpby", a=a, b=b, y=out, wa=wa, wb=wb, total=a.numel())
+        ctx.w = (wa, wb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        wa, wb = ctx.w
+        g = _req(g, "grad")
+        if wa == 1.0 and wb == 1.0:
+            return g, g, None, None
+        ga, gb = _empty(g.shape, g), _empty(g.shape, g)
+        zero = g  # b operand unused when its weight is 0
+        _k("vmtl_axpby", a=g, b=zero, y=ga, wa=wa, wb=0.0, total=g.numel())
+        _k("vmtl_axpby", a=g, b=zero, y=gb, wa=wb, wb=0.0, total=g.numel())
+        return ga, gb, None, None
+
+
+def add_losses(a, b, wa=1.0, wb=1.0):
+    return _AddScalars.apply(a, b, float(wa), float(wb))
+
+
 def argmax_channels(logits):
     """argmax over dim 1 of (B,C,H,W) logits -> int64 (B,H,W); reads NCHW or channels-last strides in place."""
     if not logits.is_cuda:
