@@ -321,3 +321,40 @@ def test_bn_act_dwconv_matches_torch(dev, case, training):
     assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="bn_act_dwconv dbeta")
     assert_close(bnd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
     assert_close(bnd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 16, 12, 20, 3, 1, "hardswish"), (1, 72, 8, 12, 5, 2, "relu"), (2, 24, 9, 7, 3, 1, "relu")])
+def test_bn_act_dwconv_returns_activation_for_a_second_consumer(dev, case):
+    """return_act=True: a = act(bn(x)) comes back as a differentiable output (the residual branch of the block) and the
+    gradient that reaches it is added inside the depthwise data gradient (vmtl_dwconv_bwd_data_add):
+    loss = <y, gy> + <a, ga> must give torch's gradients for x, the depthwise weight and the BatchNorm parameters."""
+    import copy
+
+    from vision_mtl_amd import ops
+
+    B, C, H, W, K, stride, act = case
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, C, H, W, generator=g) * 1.2 - 0.2
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g) * 0.2
+    bnd = copy.deepcopy(bn).to(dev)
+    w = torch.randn(C, 1, K, K, generator=g) / K
+    fact = {"relu": F.relu, "hardswish": F.hardswish}[act]
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ar = fact(bn(xr))
+    yr = F.conv2d(ar, wr, None, stride=stride, padding=(K - 1) // 2, groups=C)
+    gy, ga = torch.randn(yr.shape, generator=g), torch.randn(ar.shape, generator=g)
+    ((yr * gy).sum() + (ar * ga).sum()).backward()
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    y, stats, rpb, a = ops.bn_act_dwconv(xd, None, 0, bnd, C, ops.ACT_CODES[act], wd, stride, (K - 1) // 2,
+                                         want_stats=True, return_act=True)
+    assert_close(from_dev_nhwc(a, C), ar.detach(), what="returned activation")
+    assert_close(from_dev_nhwc(y, C), yr.detach(), what="fwd")
+    ((y * to_dev_nhwc(gy, dev)).sum() + (a * to_dev_nhwc(ga, dev)).sum()).backward()
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=2e-4, what="dx with the second consumer's gradient")
+    assert_close(wd.grad.cpu(), wr.grad, tol=2e-4, what="dw")
+    assert_close(bnd.weight.grad.cpu(), bn.weight.grad, tol=2e-4, what="dgamma")
+    assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="dbeta")

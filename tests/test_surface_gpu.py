@@ -364,3 +364,27 @@ def test_cross_entropy_with_argmax_matches_separate_ops():
         assert torch.equal(z1.grad, z2.grad)
         ref = torch.nn.functional.cross_entropy(z.cpu().double().requires_grad_(True), t.cpu())
         assert abs(l2.item() - ref.item()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_fork_and_add_losses_match_autograd():
+    """ops.fork (two handles on a two-consumer activation, gradients summed by vmtl_eltwise) and ops.add_losses
+    (the weighted task-loss sum of reference lit_module.py:127-129 as one vmtl_axpby launch) against plain autograd."""
+    from vision_mtl_amd import ops
+
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, 5, 7, 8, device=dev, requires_grad=True)
+    a, b = ops.fork(x)
+    (a * 2.0).sum().backward(retain_graph=True)
+    assert torch.equal(x.grad, torch.full_like(x, 2.0))  # one consumer only: its gradient passes through
+    x.grad = None
+    ((a * 2.0).sum() + (b * b).sum()).backward()
+    assert_close(x.grad.cpu(), (2.0 + 2.0 * x.detach()).cpu(), what="fork gradient sum")
+    for wa, wb in [(1.0, 1.0), (0.3, 2.5)]:
+        la = torch.tensor(1.25, device=dev, requires_grad=True)
+        lb = torch.tensor(-0.5, device=dev, requires_grad=True)
+        tot = ops.add_losses(la, lb, wa, wb)
+        assert abs(tot.item() - (wa * 1.25 + wb * -0.5)) < 1e-6
+        tot.backward()
+        assert abs(la.grad.item() - wa) < 1e-7 and abs(lb.grad.item() - wb) < 1e-7

@@ -238,22 +238,46 @@ __global__ __launch_bounds__(256) void pack_up2_dgrad_kernel(const float* __rest
 
 // folds the slabs of the low-res weight gradient G[z][c][(kh*4+kw)*Cos + n] back onto the 3x3 taps:
 // dW[n][c][dh][dw] = sum_z sum_{kh in {2-dh,3-dh}} sum_{kw in {2-dw,3-dw}} G[z][c][kh][kw][n]   (c < C0)
+// A workgroup handles 64 consecutive elements x 4 slab groups (wave w sums slabs w, w+4, ...; the four partial sums
+// are added in wave order through LDS: deterministic), two slabs' loads in flight per thread.  One thread per element
+// walking all slabs left the narrow full-resolution layers (20 K elements, 64+ slabs) with 78 workgroups of 256 serial
+// dependent loads: 96 us.
 __global__ __launch_bounds__(256) void unpack_up2_kernel(const float* __restrict__ slabs, float* __restrict__ grad,
                                                          int Cout, int Cos, int C0, int Cin, int nslabs,
                                                          long long slab_stride, long long total) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % Cout);
-    long long rest = i / Cout;
-    const int tap = (int)(rest % 9), c = (int)(rest / 9);
-    const int dh = tap / 3, dw = tap - dh * 3;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+    const long long i = base + lane;
     float s = 0.f;
-    for (int z = 0; z < nslabs; ++z) {
-      const float* g = slabs + (size_t)z * slab_stride + (size_t)c * 16 * Cos + n;
-      s += (g[((2 - dh) * 4 + (2 - dw)) * Cos] + g[((2 - dh) * 4 + (3 - dw)) * Cos]) +
-           (g[((3 - dh) * 4 + (2 - dw)) * Cos] + g[((3 - dh) * 4 + (3 - dw)) * Cos]);
+    long long dst = 0;
+    if (i < total) {
+      const int n = (int)(i % Cout);
+      const long long rest = i / Cout;
+      const int tap = (int)(rest % 9), c = (int)(rest / 9);
+      const int dh = tap / 3, dw = tap - dh * 3;
+      dst = ((long long)n * Cin + c) * 9 + tap;
+      const float* g0 = slabs + (size_t)c * 16 * Cos + n;
+      const int o00 = ((2 - dh) * 4 + (2 - dw)) * Cos, o01 = ((2 - dh) * 4 + (3 - dw)) * Cos;
+      const int o10 = ((3 - dh) * 4 + (2 - dw)) * Cos, o11 = ((3 - dh) * 4 + (3 - dw)) * Cos;
+      int z = zg;
+      for (; z + 4 < nslabs; z += 8) {
+        const float* ga = g0 + (size_t)z * slab_stride;
+        const float* gb = g0 + (size_t)(z + 4) * slab_stride;
+        const float a0 = ga[o00], a1 = ga[o01], a2 = ga[o10], a3 = ga[o11];
+        const float b0 = gb[o00], b1 = gb[o01], b2 = gb[o10], b3 = gb[o11];
+        s += (a0 + a1) + (a2 + a3);
+        s += (b0 + b1) + (b2 + b3);
+      }
+      for (; z < nslabs; z += 4) {
+        const float* ga = g0 + (size_t)z * slab_stride;
+        s += (ga[o00] + ga[o01]) + (ga[o10] + ga[o11]);
+      }
     }
-    grad[((size_t)n * Cin + c) * 9 + tap] = s;
+    red[zg][lane] = s;
+    __syncthreads();
+    if (zg == 0 && i < total) grad[dst] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    __syncthreads();
   }
 }
 
@@ -280,7 +304,9 @@ extern "C" int vmtl_unpack_up2(const float* slabs, float* grad, int Cout, int Co
   VMTL_ENTER();
   if (!slabs || !grad || Cout <= 0 || Cout > Cos || C0 <= 0 || C0 > Cin || nslabs <= 0) return VMTL_ERR_ARG;
   const long long total = (long long)C0 * 9 * Cout;
-  hipLaunchKernelGGL(unpack_up2_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, slabs, grad, Cout,
+  long long nb = cdivll(total, 64);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(unpack_up2_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, slabs, grad, Cout,
                      Cos, C0, Cin, nslabs, (long long)C0 * 16 * Cos, total);
   return vmtl_check_launch();
 }
