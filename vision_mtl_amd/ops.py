@@ -1761,6 +1761,7 @@ class _Fork(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)  # an unused handle contributes None, not a zero tensor to add
         return x.detach(), x.detach()
 
     @staticmethod
