@@ -221,3 +221,30 @@ def test_prepare_sample_and_collate_follow_the_reference_contract():
         data.prepare_sample({"img": raw["img"].transpose(2, 0, 1), "mask": raw["mask"], "depth": raw["depth"]}, C)
     sb, ob = data.synthetic_batch(2, 8, 8, 5, seed=4, masked=0.2), __import__("oracle.losses", fromlist=["x"]).synthetic_batch(2, 8, 8, 5, seed=4, masked=0.2)
     assert all(torch.equal(sb[k], ob[k]) for k in sb)  # product-side generator == the oracle's (same seeds, same draws)
+
+
+def test_flat_arena_does_not_keep_the_model_alive():
+    """The arena's gradient hooks sit in C++ autograd metadata (invisible to the cycle collector): they must not hold
+    the arena or the parameters strongly, or every model ever given an arena stays alive with its packed operands."""
+    import gc
+    import weakref
+
+    import torch
+
+    from vision_mtl_amd import dp
+
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    arena = dp.FlatArena(model, broadcast=False)
+    wm, wa, wp = weakref.ref(model), weakref.ref(arena), weakref.ref(next(model.parameters()))
+    del model, arena
+    gc.collect()
+    assert wm() is None and wa() is None and wp() is None
+
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3))
+    arena = dp.FlatArena(model, broadcast=False)
+    p = next(model.parameters())
+    assert getattr(p, "_vmtl_gslot", None) is not None
+    arena.close()
+    assert not hasattr(p, "_vmtl_gslot") and not hasattr(p, "_vmtl_arena")
+    (model(torch.randn(1, 3, 5, 5)).sum()).backward()  # ordinary autograd accumulation into the (still valid) .grad view
+    assert p.grad is not None and float(p.grad.abs().sum()) > 0

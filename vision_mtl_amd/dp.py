@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import os
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -50,6 +52,7 @@ class FlatArena:
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params, self.offsets, off = params, [], 0
         self._kernel_written = set()  # ids of parameters whose slot a HIP backward kernel writes (ops._slot)
+        self._hooks = []
         for p in params:
             n = p.numel()
             slot = self.flat_param[off:off + n].view(p.shape)
@@ -58,7 +61,7 @@ class FlatArena:
             p.grad = self.flat_grad[off:off + n].view(p.shape)
             p._vmtl_gslot = p.grad
             p._vmtl_arena = self
-            p.register_hook(self._make_mixed_use_guard(p))
+            self._hooks.append(p.register_hook(self._make_mixed_use_guard(p)))
             self.offsets.append(off)
             off += n
         self.numel = total
@@ -96,14 +99,34 @@ class FlatArena:
 
     # ---- gradient bookkeeping
     def _make_mixed_use_guard(self, p):
+        # The hook lives in the tensor's C++ autograd metadata, where Python's cycle collector cannot see it: a closure
+        # holding the arena (or p) strongly would keep arena, parameters and model alive for the life of the process
+        # (and with them their packed operands, re-packed every step: bench.py's later configurations measured up to
+        # 1 ms/step slower).  It holds a weak reference and the parameter's id instead.
+        wself, pid = weakref.ref(self), id(p)
+
         def guard(grad):
-            if grad is not None and id(p) in self._kernel_written:  # kernels that wrote the slot hand autograd None
+            arena = wself()
+            if arena is not None and grad is not None and pid in arena._kernel_written:  # kernels hand autograd None
                 raise RuntimeError(
                     "a parameter of the FlatArena receives a gradient through ordinary autograd AND from a HIP "
                     "backward kernel that overwrites its slot in the same backward pass: the result would depend on "
                     "their order.  Keep torch-native loss terms off parameters the vmtl kernels differentiate.")
             return grad
         return guard
+
+    def close(self) -> None:
+        """Detach from the model: hooks removed, kernels stop writing into the slots (the parameters keep their storage
+        inside the flat buffer and their .grad views, which stay valid tensors)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            for attr in ("_vmtl_gslot", "_vmtl_arena"):
+                if hasattr(p, attr):
+                    delattr(p, attr)
+        if getattr(self.model, "dp_arena", None) is self:
+            self.model.dp_arena = None
 
     def zero_grad(self) -> None:
         """One memset of the whole gradient buffer (slots written by kernels do not need it: they are overwritten)."""

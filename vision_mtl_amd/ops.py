@@ -283,8 +283,8 @@ class _PackCache:
     def get_custom(self, weight, kind, shape, fn, deps=()):
         """Operand built by its own kernel (fn(weight, dst) launches it): cached like get(); refresh() rebuilds
         all of them on the side stream at the start of a step, so inside the step this is a lookup (+ one
-        event wait on first use).  deps: further tensors fn reads (it may capture them; the entry lives as long as
-        `weight` does) - a change of any of them invalidates the entry like a change of `weight`."""
+        event wait on first use).  deps: further tensors fn reads (through weak references of its own: the cache must
+        not keep parameters alive) - a change of any of them invalidates the entry like a change of `weight`."""
         key = (id(weight), kind)
         e = self.custom.get(key)
         if e is not None and e["wref"]() is not weight:
@@ -1574,9 +1574,11 @@ class _DecoderTail(torch.autograd.Function):
         stamp("main tail heads")
         fork = side.mark()
         # heads' data gradient; epilogue = ReLU + BatchNorm-2 backward reduction (dz2 and its per-tile column sums)
-        def pack_heads_dgrad(w, dst, wb=wb):  # both heads' flipped weights as ONE dgrad operand [C2][9][ldyh]
+        wb_ref = weakref.ref(wb)  # the cache entry must not keep a parameter (and through it the whole model) alive
+
+        def pack_heads_dgrad(w, dst):  # both heads' flipped weights as ONE dgrad operand [C2][9][ldyh]
             pack(w, 1, C2, 9, Ca, ldyh, 0, 9, 1, C2 * 9, flip=1, out=dst)
-            _k("vmtl_pack_weights_slice", src=wb, dst=dst.view(-1)[Ca:], R0=C2, T=9, C=Cb, group=ldyh, sr0=9, st=1,
+            _k("vmtl_pack_weights_slice", src=wb_ref(), dst=dst.view(-1)[Ca:], R0=C2, T=9, C=Cb, group=ldyh, sr0=9, st=1,
                sc=C2 * 9, flip=1)
 
         wd = packs.get_custom(wa, "heads_dgrad", (C2, 9 * ldyh), pack_heads_dgrad, deps=(wb,))
