@@ -279,9 +279,14 @@ def init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        # VMTL_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+        # devices round-robin; RCCL refuses two ranks on one device)
+        backend = os.environ.get("VMTL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            if backend != "nccl":
+                local_rank %= max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local_rank)
+        if backend == "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
