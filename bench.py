@@ -98,6 +98,8 @@ def time_conv_kernels(module, batch, reps=3):
                 M, K, tag = kw["B"] * kw["Ho"] * kw["Wo"], kw["KH"] * kw["KW"] * kw["Cs"], f"k{kw['KH']}s{kw['stride']}"
             elif "Ks" in kw:
                 M, K, tag = kw["M"], kw["Ks"], "k1s1"
+            elif "K1" in kw:
+                M, K, tag = kw["M"], kw["K1"] + kw["K2s"], "k1cat"
             elif "H2" in kw:
                 M, K, tag = 4 * kw["B"] * kw["H2"] * kw["W2"], 4 * kw["C0s"] + 9 * kw["C1s"], "up2 "
             else:

@@ -63,6 +63,12 @@ int vmtl_conv1x1_stats_block(int M, int ldy, int Ks);
 int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks);
 int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,
                      int Nw, int Cout, void* stream);
+/* conv1x1(cat[x, x2]) without the concat (mtan_model.py:57-59,139-141): x [M][K1] (K1 % 4 == 0), x2 [M][K2s], packed
+ * weight rows [Nw][K1 + K2s]; and its data gradient writing [dx | dx2] (dx [M][N1], dx2 [M][N2s]) without a split pass */
+int vmtl_conv1x1_cat_fwd(const float* x, int K1, const float* x2, int K2s, const float* wp, const float* bias, float* y,
+                         float* stats, int M, int ldy, int Nw, int Cout, void* stream);
+int vmtl_conv1x1_cat_dgrad(const float* dy, const float* wp, float* dx, int N1, float* dx2, int N2s, int N2, int M,
+                           int Ks, void* stream);
 
 /* vmtl_conv2d_fwd used as a DATA GRADIENT with the BatchNorm + activation backward of the layer that produced the
  * differentiated tensor fused into the epilogue (reference utils/model_utils.py:72-76 run backwards): y = conv *

@@ -653,3 +653,46 @@ def test_layout_roundtrip_and_adam(dev):
         step += 1
         ops.adam_step(pd, gr.to(dev), m, v, step, 5e-3)
     assert_close(pd.cpu(), pr.detach(), tol=1e-6, what="adam")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 6, 9, 7, 10, True), (1, 64, 128, 16, 24, 128, True), (3, 8, 3, 5, 11, 33, False),
+                                  (2, 128, 64, 8, 8, 64, True)])
+def test_conv1x1_cat_matches_conv_on_concat(dev, case):
+    """ops.conv1x1_cat(xa, xb) == conv1x1(cat[xa, xb]) (MTAN attention conv1, reference models/mtan_model.py:57-59,
+    139-141): output, BatchNorm partial rows, both input gradients, weight and bias gradients - the concat, the
+    gradient split and the second read of the concat by the weight gradient never materialise."""
+    ops = _ops()
+    B, Ca, Cb, H, W, Cout, bias = case
+    g = torch.Generator().manual_seed(123)
+    xa, xb = torch.randn(B, Ca, H, W, generator=g), torch.randn(B, Cb, H, W, generator=g)
+    w = torch.randn(Cout, Ca + Cb, 1, 1, generator=g) / (Ca + Cb) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    xar, xbr, wr = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(torch.cat([xar, xbr], 1), wr, br)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xad, xbd = to_dev_nhwc(xa, dev).requires_grad_(True), to_dev_nhwc(xb, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    assert ops.conv1x1_cat_supported(xad, Ca, xbd)
+    y, stats = ops.conv1x1_cat(xad, xbd, Cb, wd, bd, want_stats=True)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="cat conv fwd")
+    if y.shape[-1] > Cout:
+        assert y[..., Cout:].abs().max().item() == 0.0
+    M, rpb = B * H * W, stats._vmtl_rpb
+    st = stats.double().cpu()
+    cnt = torch.tensor([max(0, min(rpb, M - i * rpb)) for i in range(st.shape[0])], dtype=torch.float64).view(-1, 1)
+    mean = (st[:, 0, :Cout] * cnt).sum(0) / M
+    var = ((st[:, 1, :Cout] + cnt * (st[:, 0, :Cout] - mean) ** 2) * (cnt > 0)).sum(0) / M
+    yo = yr.detach().double()
+    assert_close(mean, yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="cat conv stats mean")
+    assert_close(var, yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="cat conv stats var")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xad.grad, Ca), xar.grad, what="cat conv dxa")
+    assert_close(from_dev_nhwc(xbd.grad, Cb), xbr.grad, what="cat conv dxb")
+    if xbd.grad.shape[-1] > Cb:
+        assert xbd.grad[..., Cb:].abs().max().item() == 0.0
+    assert_close(wd.grad.cpu(), wr.grad, what="cat conv dw")
+    if bias:
+        assert_close(bd.grad.cpu(), br.grad, what="cat conv db")

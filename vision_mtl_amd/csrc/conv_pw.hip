@@ -26,10 +26,16 @@ struct PwP {
   float* stats;       // optional [tiles_m][2][ldy]: per-row-block column (mean, M2)
   int M, Ks, ldy, Nw, Cout;
   int tiles_m, tiles_n;
+  // virtual concat (MTAN attention, reference models/mtan_model.py:57-59,139-141): the K axis is [x | x2] - columns
+  // [0, K1) of a row come from x (row stride K1), [K1, Ks) from x2 (row stride Ks - K1); and its mirror for the data
+  // gradient: output columns [0, N1) go to y (row stride N1), [N1, ldy) to y2 (row stride ldy - N1)
+  const float* x2;  // null: single source
+  float* y2;        // null: single destination
+  int K1, N1;
 };
 
 // wave tile 32 rows x (16*TN) columns; KW waves of the workgroup split K, the other 4/KW stack along M
-template <int TN, int KW>
+template <int TN, int KW, bool SRC2 = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   constexpr int TM = 2;
   constexpr int RG = 4 / KW;        // row groups (waves along M)
@@ -48,13 +54,16 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
 
   // fragment sources: A rows m0 + rg*32 + 16 i + l15, B rows n0 + 16 j + l15; k = 16 g + 4 lq .. + 3
   const float* ap[TM];
+  const float* ap2[TM];  // SRC2: the same row of the second source, shifted so that index k addresses column k - K1
   const float* bp[TN];
   bool aok[TM], bok[TN];
+  const int lda = SRC2 ? p.K1 : p.Ks;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + rg * 32 + 16 * i + l15;
     aok[i] = m < p.M;
-    ap[i] = p.x + (size_t)(aok[i] ? m : 0) * p.Ks + 4 * lq;
+    ap[i] = p.x + (size_t)(aok[i] ? m : 0) * lda + 4 * lq;
+    ap2[i] = SRC2 ? p.x2 + (size_t)(aok[i] ? m : 0) * (p.Ks - p.K1) + 4 * lq - p.K1 : nullptr;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -73,8 +82,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   auto load = [&](int g, Frag& f) {
     const bool kok = g < G && 16 * g + 4 * lq < p.Ks;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      f.a[i] = (kok && aok[i]) ? *reinterpret_cast<const f32x4*>(ap[i] + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i) {
+      const float* src = (SRC2 && 16 * g + 4 * lq >= p.K1) ? ap2[i] : ap[i];  // K1 % 4 == 0: a quad has one source
+      f.a[i] = (kok && aok[i]) ? *reinterpret_cast<const f32x4*>(src + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       f.b[j] = (kok && bok[j]) ? *reinterpret_cast<const f32x4*>(bp[j] + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -142,7 +153,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
         if (n4 + e >= p.Cout) v[e] = 0.f;
       const int m = m0 + r;
       if (m < p.M) {
-        if (n4 < p.ldy) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n4) = v;
+        if (n4 < p.ldy) {
+          if (p.y2 == nullptr) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n4) = v;
+          else if (n4 < p.N1) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.N1 + n4) = v;
+          else *reinterpret_cast<f32x4*>(p.y2 + (size_t)m * (p.ldy - p.N1) + (n4 - p.N1)) = v;
+        }
         s1 += v;
         ++cnt;
       } else {
@@ -203,8 +218,18 @@ template <int TN, int KW>
 static int launch_pw(PwP& p, hipStream_t st) {
   p.tiles_m = cdiv(p.M, (4 / KW) * 32);
   p.tiles_n = cdiv(p.ldy, 16 * TN);
-  hipLaunchKernelGGL((pw_gemm_kernel<TN, KW>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  if (p.x2 != nullptr)
+    hipLaunchKernelGGL((pw_gemm_kernel<TN, KW, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((pw_gemm_kernel<TN, KW>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   return vmtl_check_launch();
+}
+
+static int pw_dispatch(PwP& p, hipStream_t st) {
+  int tn, kw;
+  pw_pick(p.M, p.ldy, p.Ks, &tn, &kw);
+  if (tn == 2) return kw == 4 ? launch_pw<2, 4>(p, st) : launch_pw<2, 1>(p, st);
+  return kw == 4 ? launch_pw<4, 4>(p, st) : launch_pw<4, 1>(p, st);
 }
 
 extern "C" int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int M, int Ks,
@@ -214,9 +239,35 @@ extern "C" int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bi
   if (Nw <= 0 || Nw > ldy || Cout <= 0 || Cout > Nw) return VMTL_ERR_ARG;
   PwP p;
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = Ks; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
-  int tn, kw;
-  pw_pick(M, ldy, Ks, &tn, &kw);
-  hipStream_t st = (hipStream_t)stream;
-  if (tn == 2) return kw == 4 ? launch_pw<2, 4>(p, st) : launch_pw<2, 1>(p, st);
-  return kw == 4 ? launch_pw<4, 4>(p, st) : launch_pw<4, 1>(p, st);
+  p.x2 = nullptr; p.y2 = nullptr; p.K1 = 0; p.N1 = 0;
+  return pw_dispatch(p, (hipStream_t)stream);
+}
+
+// conv1x1(cat[x, x2]) without the concat: x is [M][K1] (K1 % 4 == 0), x2 is [M][K2s], the packed weight rows are
+// [Nw][K1 + K2s] (the ordinary packing of the (Nw, K1 + C2) weight).  Statistics geometry = vmtl_conv1x1_stats_*(M, ldy,
+// K1 + K2s).
+extern "C" int vmtl_conv1x1_cat_fwd(const float* x, int K1, const float* x2, int K2s, const float* wp, const float* bias,
+                                    float* y, float* stats, int M, int ldy, int Nw, int Cout, void* stream) {
+  VMTL_ENTER();
+  if (!x || !x2 || !wp || !y || M <= 0 || K1 <= 0 || (K1 & 3) || K2s <= 0 || (K2s & 3) || ldy <= 0 || (ldy & 3))
+    return VMTL_ERR_ARG;
+  if (Nw <= 0 || Nw > ldy || Cout <= 0 || Cout > Nw) return VMTL_ERR_ARG;
+  PwP p;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = K1 + K2s; p.ldy = ldy; p.Nw = Nw;
+  p.Cout = Cout; p.x2 = x2; p.y2 = nullptr; p.K1 = K1; p.N1 = 0;
+  return pw_dispatch(p, (hipStream_t)stream);
+}
+
+// its data gradient: [dx | dx2] = dy * W without a split pass: output columns [0, N1) (N1 % 4 == 0) land in dx
+// ([M][N1]), columns [N1, N1 + N2s) in dx2 ([M][N2s]; columns past the N2 real ones are zero).  wp: [N1 + N2][Ks].
+extern "C" int vmtl_conv1x1_cat_dgrad(const float* dy, const float* wp, float* dx, int N1, float* dx2, int N2s, int N2,
+                                      int M, int Ks, void* stream) {
+  VMTL_ENTER();
+  if (!dy || !wp || !dx || !dx2 || M <= 0 || Ks <= 0 || (Ks & 3) || N1 <= 0 || (N1 & 3) || N2s <= 0 || (N2s & 3) ||
+      N2 <= 0 || N2 > N2s)
+    return VMTL_ERR_ARG;
+  PwP p;
+  p.x = dy; p.wp = wp; p.bias = nullptr; p.y = dx; p.stats = nullptr; p.M = M; p.Ks = Ks; p.ldy = N1 + N2s;
+  p.Nw = N1 + N2; p.Cout = N1 + N2; p.x2 = nullptr; p.y2 = dx2; p.K1 = 0; p.N1 = N1;
+  return pw_dispatch(p, (hipStream_t)stream);
 }

@@ -65,10 +65,21 @@ def conv(x: Act, m: nn.Conv2d) -> Act:
     return Act(y, m.out_channels)
 
 
-def conv_bn_act(x: Act, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | None = None,
+def conv_bn_act(x, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | None = None,
                 res: Act | None = None) -> Act:
-    """act(BN(conv(x))) [* mul] [+ res] with the BatchNorm column sums taken from the conv epilogue."""
+    """act(BN(conv(x))) [* mul] [+ res] with the BatchNorm column sums taken from the conv epilogue.
+    x: an Act, or a pair (xa, xb) standing for torch.cat((xa, xb), dim=1): a 1x1 conv then reads both maps directly
+    (ops.conv1x1_cat), anything else gets the materialised concat."""
     train = bn.training
+    if isinstance(x, tuple):
+        xa, xb = x
+        if (c.groups == 1 and c.kernel_size == (1, 1) and _pair(c.stride) == 1 and _pair(c.padding) == 0
+                and xa.hw == xb.hw and ops.conv1x1_cat_supported(xa.t, xa.C, xb.t)):
+            y, stats = ops.conv1x1_cat(xa.t, xb.t, xb.C, c.weight, c.bias, want_stats=train,
+                                       zero_bias_grad=train and c.bias is not None)
+            return bn_act(Act(y, c.out_channels), bn, act, mul, res, stats,
+                          stats_rpb=getattr(stats, "_vmtl_rpb", 0) if stats is not None else 0)
+        x = cat(xa, xb)
     if c.groups == 1:
         out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train,
                          zero_bias_grad=train and c.bias is not None)

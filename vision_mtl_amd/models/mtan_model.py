@@ -21,7 +21,7 @@ from ..utils.model_utils import DoubleConv
 class _Attention(nn.Module):
     """Shared tail of both attention modules: 1x1 -> BN -> ReLU -> 1x1 -> BN -> sigmoid gate."""
 
-    def _mask_and_gate(self, merged: L.Act, shared2: L.Act) -> L.Act:
+    def _mask_and_gate(self, merged, shared2: L.Act) -> L.Act:  # merged: an Act or the pair a torch.cat would join
         a = L.conv_bn_act(merged, self.conv1, self.bn1, ACT_RELU)
         return L.conv_bn_act(a, self.conv2, self.bn2, ACT_SIGMOID, mul=shared2)  # shared2 * sigmoid(bn2(..))
 
@@ -46,7 +46,7 @@ class AttentionModuleEncoder(_Attention):
             merged = conv1_shared
         else:
             assert prev_layer_outs is not None, "prev_layer_outs must be provided for non-first AttentionModuleEncoder"
-            merged = L.cat(conv1_shared, prev_layer_outs)
+            merged = (conv1_shared, prev_layer_outs)  # read by conv1 as two sources: no concat pass
         g = self._mask_and_gate(merged, conv2_shared)
         return L.maxpool2(L.conv_bn_act(g, self.conv3, self.bn3, ACT_RELU))
 
@@ -71,7 +71,7 @@ class AttentionModuleDecoder(_Attention):
         if conv1_shared.hw != p.hw:
             p = L.bilinear_up2(p)
         assert conv1_shared.hw == conv2_shared.hw
-        g = self._mask_and_gate(L.cat(conv1_shared, p), conv2_shared)
+        g = self._mask_and_gate((conv1_shared, p), conv2_shared)
         return L.conv_bn_act(g, self.conv_out, self.bn_out, ACT_RELU)
 
 

@@ -537,6 +537,90 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _Conv1x1Cat(torch.autograd.Function):
+    """(y, stats) = conv1x1(cat[xa, xb], weight) (+ bias) WITHOUT the concat (MTAN attention modules, reference
+    models/mtan_model.py:57-59,139-141): the pointwise GEMM reads its K axis from two tensors, its data gradient
+    writes the two input gradients directly, the weight gradient is taken per source into the two column ranges of dW.
+    xa must fill its storage (Ca % 4 == 0) so that the ordinary packing of the (Cout, Ca + Cb) weight is the operand."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, weight, bias, Cb, want_stats, zero_bias_grad):
+        xa, xb, weight = _req(xa, "xa"), _req(xb, "xb"), _req(weight, "weight")
+        B, H, W, Ca = xa.shape
+        Cbs = xb.shape[3]
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if tuple(xb.shape[:3]) != (B, H, W) or tuple(weight.shape[2:]) != (1, 1) or Cin != Ca + Cb or ceil4(Cb) != Cbs:
+            raise ValueError("conv1x1_cat: weight must be (Cout, Ca + Cb, 1, 1) over two maps of equal extent")
+        M, Ks, ldy = B * H * W, Ca + Cbs, ceil4(Cout)
+        wp = packs.get(weight, "fwd", (1, Cout, 1, Cin, Ks, 0, Cin, 1, 1, 0))
+        y = _empty((B, H, W, ldy), xa)
+        stats = None
+        if want_stats:
+            stats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Ks), 2, ldy), xa)
+        _k("vmtl_conv1x1_cat_fwd", _flop=2.0 * M * Cout * Cin, x=xa, K1=Ca, x2=xb, K2s=Cbs, wp=wp, bias=bias, y=y, stats=stats,
+           M=M, ldy=ldy, Nw=Cout, Cout=Cout)
+        ctx.save_for_backward(xa, xb, weight)
+        ctx.cfg = (Cb, bias is not None, bool(zero_bias_grad))
+        ctx.slots = (_slot(weight), _slot(bias))
+        ctx.set_materialize_grads(False)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        xa, xb, weight = ctx.saved_tensors
+        Cb, has_bias, zero_bias = ctx.cfg
+        if dy is None:
+            return (None,) * 7
+        dy = _req(dy, "dy")
+        B, H, W, Ca = xa.shape
+        Cbs = xb.shape[3]
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        M, ldy = B * H * W, dy.shape[3]
+        sw, sbias = ctx.slots
+        dxa = dxb = dw = db = None
+        fork = side.mark()
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wd = packs.get(weight, "dgrad", (1, Cin, 1, Cout, ldy, 0, 1, 1, Cin, 1))  # [Cin][ldy]
+            dxa, dxb = _empty(xa.shape, xa), _empty(xb.shape, xa)
+            _k("vmtl_conv1x1_cat_dgrad", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, dx=dxa, N1=Ca, dx2=dxb, N2s=Cbs, N2=Cb,
+               M=M, Ks=ldy)
+        if ctx.needs_input_grad[2]:
+            with side.branch(sw is not None, M, fork, xa, xb, dy):
+                dwt = _empty(weight.shape, xa) if sw is None else sw
+                flat = dwt.view(-1)
+                sl, ns = _wgrad(xa, dy, B, H, W, Ca, H, W, ldy, Cout, 1, 1, 1, 0, 2.0 * M * Cout * Ca)
+                unpack(sl, None, 1, Cout, 1, Ca, Ca, 0, Cin, 1, 1, out=flat, nslabs=ns)
+                sl, ns = _wgrad(xb, dy, B, H, W, Cbs, H, W, ldy, Cout, 1, 1, 1, 0, 2.0 * M * Cout * Cb)
+                unpack(sl, None, 1, Cout, 1, Cb, Cbs, 0, Cin, 1, 1, out=flat[Ca:], nslabs=ns)
+            dw = None if sw is not None else dwt
+        if has_bias and ctx.needs_input_grad[3]:
+            with side.branch(sbias is not None, M, fork, dy):
+                if zero_bias:
+                    db = _empty((Cout,), xa) if sbias is None else sbias
+                    _k("vmtl_fill_zero", p=db, n=Cout)
+                else:
+                    db = _colsum(dy, None, M, Cout, ldy, out=sbias)
+            if sbias is not None:
+                db = None
+        return dxa, dxb, dw, db, None, None, None
+
+
+def conv1x1_cat_supported(xa, Ca, xb):
+    return _PW and Ca % 4 == 0 and xa.shape[3] == Ca and xa.shape[0] * xa.shape[1] * xa.shape[2] <= _PW_MAX_ROWS \
+        and tuple(xa.shape[:3]) == tuple(xb.shape[:3]) and os.environ.get("VMTL_CAT_CONV", "1") != "0"
+
+
+def conv1x1_cat(xa, xb, Cb, weight, bias=None, want_stats=False, zero_bias_grad=False):
+    """conv1x1(cat[xa, xb]) without materialising the concat; returns (y, stats-or-None)."""
+    y, stats = _Conv1x1Cat.apply(xa, xb, weight, bias, Cb, want_stats, zero_bias_grad)
+    if stats is not None:
+        stats._vmtl_rpb = lib().raw("vmtl_conv1x1_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3],
+                                                                xa.shape[3] + xb.shape[3])
+    return y, stats
+
+
 class _Up2Conv(torch.autograd.Function):
     """conv3x3(pad 1, no bias)(cat[nearest_x2(xl), skip]) - the entry of every smp U-Net decoder block
     (reference utils/model_utils.py:25-34) - without materialising the upsample or the concat and with 4
