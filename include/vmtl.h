@@ -69,6 +69,17 @@ int vmtl_conv1x1_cat_fwd(const float* x, int K1, const float* x2, int K2s, const
                          float* stats, int M, int ldy, int Nw, int Cout, void* stream);
 int vmtl_conv1x1_cat_dgrad(const float* dy, const float* wp, float* dx, int N1, float* dx2, int N2s, int N2, int M,
                            int Ks, void* stream);
+/* pointwise pre-activation node (the 1x1 counterpart of vmtl_conv3x3_small's prologue / vmtl_conv2d_bnbwd):
+ * y = conv1x1(act(coef_a[k]*x + coef_c[k])) - BatchNorm + activation (none / relu / hardswish) of the layer that produced
+ * x applied to the operand fragments, a_out (nullable [M][Ks]) = the activated matrix for the weight gradient;
+ * and the data gradient ending with that activation's + BatchNorm's backward: dz = (dy*W) * act'(gamma*xhat + beta),
+ * stats [vmtl_conv1x1_stats_rows(M, ldy, Ks)][2][ldy] = per-row-block (sum dz, sum dz*xhat). */
+int vmtl_conv1x1_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act_in, float* a_out,
+                        const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy, int Nw,
+                        int Cout, void* stream);
+int vmtl_conv1x1_bnbwd(const float* dy, const float* wp, float* dz, float* stats, const float* ez_x,
+                       const float* ez_mean, const float* ez_invstd, const float* ez_gamma, const float* ez_beta,
+                       int ez_act, int M, int Ks, int ldy, int Nw, int Cout, void* stream);
 
 /* vmtl_conv2d_fwd used as a DATA GRADIENT with the BatchNorm + activation backward of the layer that produced the
  * differentiated tensor fused into the epilogue (reference utils/model_utils.py:72-76 run backwards): y = conv *

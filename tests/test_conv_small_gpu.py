@@ -358,3 +358,64 @@ def test_bn_act_dwconv_returns_activation_for_a_second_consumer(dev, case):
     assert_close(wd.grad.cpu(), wr.grad, tol=2e-4, what="dw")
     assert_close(bnd.weight.grad.cpu(), bn.weight.grad, tol=2e-4, what="dgamma")
     assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="dbeta")
+
+
+# B, C, H, W, Cout, act, bias
+BNPW_CASES = [(2, 16, 12, 20, 24, "relu", True), (1, 72, 8, 8, 24, "relu", False), (2, 128, 16, 16, 64, "relu", True),
+              (1, 240, 4, 8, 40, "hardswish", False), (2, 64, 9, 7, 130, "relu", True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("case", BNPW_CASES)
+def test_bn_act_conv1x1_matches_torch(dev, case, training):
+    """ops.bn_act_conv1x1 (BatchNorm + activation on the pointwise GEMM's operand fragments, BatchNorm-backward
+    reduction in the data gradient's epilogue) == conv1x1(act(bn(x))) in torch: values, output statistics, every
+    gradient, running buffers; K-split and plain tilings, 32- and 64-column tiles."""
+    import copy
+
+    from vision_mtl_amd import ops
+
+    B, C, H, W, Cout, act, bias = case
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn(B, C, H, W, generator=g) * 1.3 + 0.2
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g) * 0.2
+    bn.running_mean.data = torch.randn(C, generator=g) * 0.1
+    bn.running_var.data = torch.rand(C, generator=g) + 0.5
+    bn.train(training)
+    bnd = copy.deepcopy(bn).to(dev)
+    w = torch.randn(Cout, C, 1, 1, generator=g) / C ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    fact = {"relu": F.relu, "hardswish": F.hardswish}[act]
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(fact(bn(xr)), wr, br)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    assert ops.bn_act_conv1x1_supported(xd, ops.ACT_CODES[act])
+    y, stats, rpb = ops.bn_act_conv1x1(xd, None, 0, bnd, C, ops.ACT_CODES[act], wd, bd, want_stats=True)
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="bn_act_conv1x1 fwd")
+    if y.shape[-1] > Cout:
+        assert y[..., Cout:].abs().max().item() == 0.0
+    M = B * H * W
+    st = stats.cpu().double()
+    cnt = torch.tensor([max(0, min(rpb, M - i * rpb)) for i in range(st.shape[0])], dtype=torch.float64).view(-1, 1)
+    mean = (st[:, 0, :Cout] * cnt).sum(0) / M
+    var = ((st[:, 1, :Cout] + cnt * (st[:, 0, :Cout] - mean) ** 2) * (cnt > 0)).sum(0) / M
+    yo = yr.detach().double()
+    assert_close(mean, yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="pw output stats mean")
+    assert_close(var, yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="pw output stats var")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=2e-4, what="bn_act_conv1x1 dx")
+    assert_close(wd.grad.cpu(), wr.grad, tol=2e-4, what="bn_act_conv1x1 dw")
+    assert_close(bnd.weight.grad.cpu(), bn.weight.grad, tol=2e-4, what="bn_act_conv1x1 dgamma")
+    assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="bn_act_conv1x1 dbeta")
+    if bias:
+        assert_close(bd.grad.cpu(), br.grad, tol=2e-4, what="bn_act_conv1x1 dbias")
+    assert_close(bnd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
+    assert_close(bnd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")

@@ -32,10 +32,26 @@ struct PwP {
   const float* x2;  // null: single source
   float* y2;        // null: single destination
   int K1, N1;
+  // pre-activation node (PRO): the A operand is act(pa[k] * x + pc[k]) - BatchNorm + activation of the layer that
+  // produced x, applied to the fragments on their way into the MFMAs; a_out (nullable) receives the activated matrix
+  // once (workgroups of column tile 0), for the weight-gradient kernel
+  const float* pa;
+  const float* pc;
+  float* a_out;
+  int act_in;
+  // BatchNorm-backward epilogue (ez_x != null): the launch is the data gradient of a conv whose input was
+  // act(BN(ez_x)); it stores dz = acc * act'(gamma * xhat + beta) instead of acc and per-row-block (sum dz,
+  // sum dz * xhat) in `stats` - the BatchNorm backward then needs no reduction pass of its own
+  const float* ez_x;
+  const float* ez_mean;
+  const float* ez_invstd;
+  const float* ez_gamma;
+  const float* ez_beta;
+  int ez_act;
 };
 
 // wave tile 32 rows x (16*TN) columns; KW waves of the workgroup split K, the other 4/KW stack along M
-template <int TN, int KW, bool SRC2 = false>
+template <int TN, int KW, bool SRC2 = false, bool PRO = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   constexpr int TM = 2;
   constexpr int RG = 4 / KW;        // row groups (waves along M)
@@ -78,9 +94,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  struct Frag { f32x4 a[TM], b[TN]; };
+  struct Frag { f32x4 a[TM], b[TN], pa, pc; };
   auto load = [&](int g, Frag& f) {
     const bool kok = g < G && 16 * g + 4 * lq < p.Ks;
+    if (PRO) {
+      f.pa = kok ? *reinterpret_cast<const f32x4*>(p.pa + 16 * g + 4 * lq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f.pc = kok ? *reinterpret_cast<const f32x4*>(p.pc + 16 * g + 4 * lq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const float* src = (SRC2 && 16 * g + 4 * lq >= p.K1) ? ap2[i] : ap[i];  // K1 % 4 == 0: a quad has one source
@@ -90,7 +110,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
     for (int j = 0; j < TN; ++j)
       f.b[j] = (kok && bok[j]) ? *reinterpret_cast<const f32x4*>(bp[j] + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
   };
-  auto mma = [&](const Frag& f) {
+  auto mma = [&](Frag& f, int g) {
+    if (PRO) {  // the producer's BatchNorm + activation, on the fragments (k >= Ks: pa = pc = 0 and B is zero there)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        f32x4 v = f.a[i] * f.pa + f.pc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act_in);
+        f.a[i] = v;
+        if (p.a_out != nullptr && tile_n == 0 && aok[i] && g < G && 16 * g + 4 * lq < p.Ks)
+          *reinterpret_cast<f32x4*>(p.a_out + (size_t)(m0 + rg * 32 + 16 * i + l15) * p.Ks + 16 * g + 4 * lq) = v;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -106,13 +137,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   load(g + KW, f1);
   for (; g < G; g += 3 * KW) {
     load(g + 2 * KW, f2);
-    mma(f0);
+    mma(f0, g);
     if (g + KW >= G) break;
     load(g + 3 * KW, f0);
-    mma(f1);
+    mma(f1, g + KW);
     if (g + 2 * KW >= G) break;
     load(g + 4 * KW, f1);
-    mma(f2);
+    mma(f2, g + 2 * KW);
   }
 
   // ---- C layout -> LDS (one plane per K slice); C: column = lane & 15, row = 4 * (lane >> 4) + reg ----
@@ -138,6 +169,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   }
   f32x4 val[PASSES];
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s2x = {0.f, 0.f, 0.f, 0.f};  // BatchNorm-backward epilogue: sum dz * xhat
+  const bool ez = p.ez_x != nullptr;
+  f32x4 e_mean = {0.f, 0.f, 0.f, 0.f}, e_is = e_mean, e_g = e_mean, e_b = e_mean;
+  if (ez && n4 < p.ldy) {
+    e_mean = *reinterpret_cast<const f32x4*>(p.ez_mean + n4);
+    e_is = *reinterpret_cast<const f32x4*>(p.ez_invstd + n4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      e_g[e] = n4 + e < p.Cout ? (p.ez_gamma ? p.ez_gamma[n4 + e] : 1.f) : 0.f;
+      e_b[e] = n4 + e < p.Cout ? (p.ez_beta ? p.ez_beta[n4 + e] : 0.f) : 0.f;
+    }
+  }
   int cnt = 0;
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
@@ -152,6 +195,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
       for (int e = 0; e < 4; ++e)
         if (n4 + e >= p.Cout) v[e] = 0.f;
       const int m = m0 + r;
+      if (ez && m < p.M && n4 < p.ldy) {
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(p.ez_x + (size_t)m * p.ldy + n4) - e_mean) * e_is;
+        const f32x4 z = e_g * xh + e_b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], p.ez_act);
+        s2x += v * xh;
+      }
       if (m < p.M) {
         if (n4 < p.ldy) {
           if (p.y2 == nullptr) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n4) = v;
@@ -166,7 +216,22 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
     }
     val[ps] = v;
   }
-  if (p.stats != nullptr) {
+  if (p.stats != nullptr && ez) {
+    // per-tile (sum dz, sum dz * xhat) of every column
+    red[0][tid] = s1;
+    red[1][tid] = s2x;
+    __syncthreads();
+    if (tid < Q && n4 < p.ldy) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+#pragma unroll
+      for (int k = 0; k < RPP; ++k) {
+        a += red[0][tid + Q * k];
+        c += red[1][tid + Q * k];
+      }
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = a;
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = c;
+    }
+  } else if (p.stats != nullptr) {
     // per-tile (mean, M2) of every column: rows of a column live in the RPP threads tid = q + Q * r0
     const int nvalid = min(BM, p.M - m0);
     red[0][tid] = s1;
@@ -220,9 +285,16 @@ static int launch_pw(PwP& p, hipStream_t st) {
   p.tiles_n = cdiv(p.ldy, 16 * TN);
   if (p.x2 != nullptr)
     hipLaunchKernelGGL((pw_gemm_kernel<TN, KW, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  else if (p.pa != nullptr)
+    hipLaunchKernelGGL((pw_gemm_kernel<TN, KW, false, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((pw_gemm_kernel<TN, KW>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
   return vmtl_check_launch();
+}
+
+static void pw_plain(PwP& p) {  // no prologue, ordinary epilogue
+  p.pa = p.pc = nullptr; p.a_out = nullptr; p.act_in = 0;
+  p.ez_x = p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = nullptr; p.ez_act = 0;
 }
 
 static int pw_dispatch(PwP& p, hipStream_t st) {
@@ -240,6 +312,7 @@ extern "C" int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bi
   PwP p;
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = Ks; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.x2 = nullptr; p.y2 = nullptr; p.K1 = 0; p.N1 = 0;
+  pw_plain(p);
   return pw_dispatch(p, (hipStream_t)stream);
 }
 
@@ -255,6 +328,7 @@ extern "C" int vmtl_conv1x1_cat_fwd(const float* x, int K1, const float* x2, int
   PwP p;
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = K1 + K2s; p.ldy = ldy; p.Nw = Nw;
   p.Cout = Cout; p.x2 = x2; p.y2 = nullptr; p.K1 = K1; p.N1 = 0;
+  pw_plain(p);
   return pw_dispatch(p, (hipStream_t)stream);
 }
 
@@ -269,5 +343,44 @@ extern "C" int vmtl_conv1x1_cat_dgrad(const float* dy, const float* wp, float* d
   PwP p;
   p.x = dy; p.wp = wp; p.bias = nullptr; p.y = dx; p.stats = nullptr; p.M = M; p.Ks = Ks; p.ldy = N1 + N2s;
   p.Nw = N1 + N2; p.Cout = N1 + N2; p.x2 = nullptr; p.y2 = dx2; p.K1 = 0; p.N1 = N1;
+  pw_plain(p);
+  return pw_dispatch(p, (hipStream_t)stream);
+}
+
+// conv1x1(act(coef_a[k] * x + coef_c[k])): the BatchNorm + activation of the layer that produced x (coefficients from
+// vmtl_bn_stats_coef; act in {none, relu, hardswish}: act(0) must be 0 on the pad channels) applied to the operand
+// fragments; a_out (nullable, [M][Ks]) receives the activated matrix for the weight gradient.
+extern "C" int vmtl_conv1x1_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act_in, float* a_out,
+                                   const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,
+                                   int Nw, int Cout, void* stream) {
+  VMTL_ENTER();
+  if (!x || !coef_a || !coef_c || !wp || !y || M <= 0 || Ks <= 0 || (Ks & 3) || ldy <= 0 || (ldy & 3)) return VMTL_ERR_ARG;
+  if (Nw <= 0 || Nw > ldy || Cout <= 0 || Cout > Nw) return VMTL_ERR_ARG;
+  if (act_in != VMTL_ACT_NONE && act_in != VMTL_ACT_RELU && act_in != VMTL_ACT_HSWISH) return VMTL_ERR_ARG;
+  PwP p;
+  p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = Ks; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
+  p.x2 = nullptr; p.y2 = nullptr; p.K1 = 0; p.N1 = 0;
+  pw_plain(p);
+  p.pa = coef_a; p.pc = coef_c; p.a_out = a_out; p.act_in = act_in;
+  return pw_dispatch(p, (hipStream_t)stream);
+}
+
+// data gradient of a 1x1 conv whose input was act(BN(ez_x)), ending with that activation's and BatchNorm's backward:
+// dz [M][ldy] = (dy * W) * act'(gamma * xhat + beta), stats [vmtl_conv1x1_stats_rows(M, ldy, Ks)][2][ldy] =
+// per-row-block (sum dz, sum dz * xhat) for vmtl_bn_bwd_finalize / vmtl_bn_bwd_apply.
+extern "C" int vmtl_conv1x1_bnbwd(const float* dy, const float* wp, float* dz, float* stats, const float* ez_x,
+                                  const float* ez_mean, const float* ez_invstd, const float* ez_gamma,
+                                  const float* ez_beta, int ez_act, int M, int Ks, int ldy, int Nw, int Cout,
+                                  void* stream) {
+  VMTL_ENTER();
+  if (!dy || !wp || !dz || !stats || !ez_x || !ez_mean || !ez_invstd || M <= 0 || Ks <= 0 || (Ks & 3) || ldy <= 0 ||
+      (ldy & 3))
+    return VMTL_ERR_ARG;
+  if (Nw <= 0 || Nw > ldy || Cout <= 0 || Cout > Nw) return VMTL_ERR_ARG;
+  PwP p;
+  p.x = dy; p.wp = wp; p.bias = nullptr; p.y = dz; p.stats = stats; p.M = M; p.Ks = Ks; p.ldy = ldy; p.Nw = Nw;
+  p.Cout = Cout; p.x2 = nullptr; p.y2 = nullptr; p.K1 = 0; p.N1 = 0;
+  pw_plain(p);
+  p.ez_x = ez_x; p.ez_mean = ez_mean; p.ez_invstd = ez_invstd; p.ez_gamma = ez_gamma; p.ez_beta = ez_beta; p.ez_act = ez_act;
   return pw_dispatch(p, (hipStream_t)stream);
 }

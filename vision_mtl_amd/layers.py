@@ -91,6 +91,22 @@ def conv_bn_act(x, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | None =
     return bn_act(Act(y, c.out_channels), bn, act, mul, res, stats)
 
 
+def conv_raw(x, c: nn.Conv2d, train: bool):
+    """(raw output, BatchNorm partial rows or None, pixels per row) of a dense conv whose BatchNorm + activation the
+    NEXT layer applies (pre-activation chains); x: an Act or a pair standing for their concat (1x1 convs only)."""
+    zb = train and c.bias is not None
+    if isinstance(x, tuple):
+        xa, xb = x
+        if (c.kernel_size == (1, 1) and _pair(c.stride) == 1 and _pair(c.padding) == 0 and xa.hw == xb.hw
+                and ops.conv1x1_cat_supported(xa.t, xa.C, xb.t)):
+            y, stats = ops.conv1x1_cat(xa.t, xb.t, xb.C, c.weight, c.bias, want_stats=train, zero_bias_grad=zb)
+            return y, stats, getattr(stats, "_vmtl_rpb", 0) if stats is not None else 0
+        x = cat(xa, xb)
+    out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train, zero_bias_grad=zb)
+    y, stats = out if train else (out, None)
+    return y, stats, getattr(stats, "_vmtl_rpb", 0) if stats is not None else 0
+
+
 def bn_act(x: Act, bn: nn.BatchNorm2d, act: int, mul: Act | None = None, res: Act | None = None,
            stats=None, stats_rpb: int = 0) -> Act:
     momentum = _momentum(bn)

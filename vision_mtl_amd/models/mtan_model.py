@@ -22,6 +22,17 @@ class _Attention(nn.Module):
     """Shared tail of both attention modules: 1x1 -> BN -> ReLU -> 1x1 -> BN -> sigmoid gate."""
 
     def _mask_and_gate(self, merged, shared2: L.Act) -> L.Act:  # merged: an Act or the pair a torch.cat would join
+        c1, c2 = self.conv1, self.conv2
+        if (c1.groups == 1 and c2.kernel_size == (1, 1) and c2.groups == 1 and L._pair(c2.stride) == 1
+                and L._pair(c2.padding) == 0 and self.bn1.momentum is not None
+                and L.ops.bn_act_conv1x1_supported((merged[0] if isinstance(merged, tuple) else merged).t, ACT_RELU)):
+            # conv1 hands its raw output to conv2, which applies bn1 + ReLU on its operand fragments and whose data
+            # gradient ends with their backward reduction: no apply pass forward, no reduce pass backward
+            raw1, st1, rpb1 = L.conv_raw(merged, c1, self.bn1.training)
+            train2 = self.bn2.training
+            raw2, st2, rpb2 = L.ops.bn_act_conv1x1(raw1, st1, rpb1, self.bn1, c1.out_channels, ACT_RELU, c2.weight, c2.bias,
+                                                   want_stats=train2, zero_bias_grad=train2 and c2.bias is not None)
+            return L.bn_act(L.Act(raw2, c2.out_channels), self.bn2, ACT_SIGMOID, mul=shared2, stats=st2, stats_rpb=rpb2)
         a = L.conv_bn_act(merged, self.conv1, self.bn1, ACT_RELU)
         return L.conv_bn_act(a, self.conv2, self.bn2, ACT_SIGMOID, mul=shared2)  # shared2 * sigmoid(bn2(..))
 

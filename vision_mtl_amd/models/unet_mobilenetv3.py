@@ -141,6 +141,14 @@ class InvertedResidual(nn.Module):
             dw = self.conv_dw
             raw2, st2, rpb2 = ops.bn_act_dwconv(raw1, st1, rpb1, self.bn1, dw.out_channels, self.bn1.act_code, dw.weight,
                                                 L._pair(dw.stride), L._pair(dw.padding), want_stats=self.bn2.training)
+            if (not isinstance(self.se, SqueezeExcite) and self.bn2.momentum is not None
+                    and ops.bn_act_conv1x1_supported(raw2, self.bn2.act_code)):
+                # no squeeze-excite between bn2 and conv_pwl: conv_pwl applies bn2 + act on its operand fragments and
+                # its data gradient ends with their backward reduction
+                raw3, st3, rpb3 = ops.bn_act_conv1x1(raw2, st2, rpb2, self.bn2, dw.out_channels, self.bn2.act_code,
+                                                     self.conv_pwl.weight, None, want_stats=self.bn3.training)
+                return L.bn_act(L.Act(raw3, self.conv_pwl.out_channels), self.bn3, ACT_NONE, res=res, stats=st3,
+                                stats_rpb=rpb3)
             y = L.bn_act(L.Act(raw2, dw.out_channels), self.bn2, self.bn2.act_code, stats=st2, stats_rpb=rpb2)
         else:
             y = L.conv_bn_act(x, self.conv_pw, self.bn1, self.bn1.act_code)

@@ -537,6 +537,106 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _BNActPw(torch.autograd.Function):
+    """(y, stats) = conv1x1(act(BN(x))) (+ bias): a 1x1 conv that owns the BatchNorm + activation of its producer
+    (timm InvertedResidual bn2 + act -> conv_pwl [3P]; MTAN attention bn1 + ReLU -> conv2, reference
+    models/mtan_model.py:60-66,142-148) - the pointwise counterpart of _BNActConv.  x is the RAW output of the
+    producing conv with its BatchNorm partial rows; normalise + activation run on the GEMM's operand fragments
+    (vmtl_conv1x1_bn_fwd; the activated matrix is written back once for the weight gradient), and the data gradient
+    ends with the activation's and BatchNorm's backward reduction (vmtl_conv1x1_bnbwd): no apply pass forward, no
+    reduce pass backward."""
+
+    @staticmethod
+    def forward(ctx, x, stats, rpb, gamma, beta, rm, rv, nbt, weight, bias, cfg):
+        C, training, momentum, eps, act, want_stats, zero_bias_grad = cfg
+        x, weight = _req(x, "x"), _req(weight, "weight")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if ceil4(C) != Cs or Cin != C or tuple(weight.shape[2:]) != (1, 1):
+            raise ValueError("bn_act_conv1x1: (Cout, C, 1, 1) weight over x's channels expected")
+        mean, invstd, ca, cc = _bn_fwd_coef(x, stats, rpb, gamma, beta, rm, rv, nbt, C, training, momentum, eps)
+        wp = packs.get(weight, "fwd", (1, Cout, 1, Cin, Cs, 0, Cin, 1, 1, 0))
+        ldy = ceil4(Cout)
+        a, y = _empty(x.shape, x), _empty((B, H, W, ldy), x)
+        ostats = None
+        if want_stats:
+            ostats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs), 2, ldy), x)
+        _k("vmtl_conv1x1_bn_fwd", _flop=2.0 * M * Cout * Cin, x=x, coef_a=ca, coef_c=cc, act_in=act, a_out=a, wp=wp, bias=bias,
+           y=y, stats=ostats, M=M, Ks=Cs, ldy=ldy, Nw=Cout, Cout=Cout)
+        ctx.save_for_backward(x, a, weight, mean, invstd, gamma, beta)
+        ctx.cfg = (C, training, act, bias is not None, bool(zero_bias_grad))
+        ctx.slots = (_slot(gamma), _slot(beta), _slot(weight), _slot(bias))
+        ctx.set_materialize_grads(False)
+        if ostats is not None:
+            ctx.mark_non_differentiable(ostats)
+        return y, ostats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, a, weight, mean, invstd, gamma, beta = ctx.saved_tensors
+        C, training, act, has_bias, zero_bias = ctx.cfg
+        sg, sb, sw, sbias = ctx.slots
+        if dy is None:
+            return (None,) * 11
+        dy = _req(dy, "dy")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        ldy = dy.shape[3]
+        fork = side.mark()
+        # ---- data gradient w.r.t. a = act(BN(x)), with act' and the BatchNorm-backward column sums in the epilogue
+        wd = packs.get(weight, "dgrad", (1, Cin, 1, Cout, ldy, 0, 1, 1, Cin, 1))
+        dgamma = _empty((C,), x) if sg is None else sg
+        dbeta = _empty((C,), x) if sb is None else sb
+        dz = _empty(x.shape, x)
+        rows = lib().raw("vmtl_conv1x1_stats_rows")(M, Cs, ldy)
+        part = _empty((rows, 2, Cs), x)
+        _k("vmtl_conv1x1_bnbwd", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, dz=dz, stats=part, ez_x=x, ez_mean=mean,
+           ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, M=M, Ks=ldy, ldy=Cs, Nw=Cin, Cout=Cin)
+        _k("vmtl_bn_bwd_finalize", partial=part, nblk=rows, M=M, C=C, Cs=Cs, sum_dz=dbeta, sum_dzx=dgamma, mean=None,
+           invstd=None, gamma=None, training=1 if training else 0, coef_a=None, coef_b=None, coef_c=None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x.shape, x)
+            _k("vmtl_bn_bwd_apply", x=x, dz=dz, mean=mean, invstd=invstd, gamma=gamma, sum_dz=dbeta, sum_dzx=dgamma, dx=dx,
+               M=M, C=C, Cs=Cs, training=1 if training else 0)
+        # ---- parameter gradients (side stream when they go to arena slots)
+        dw = _empty(weight.shape, x) if sw is None else sw
+        with side.branch(sw is not None, M, fork, dy, a):
+            slabs, ns = _wgrad(a, dy, B, H, W, Cs, H, W, ldy, Cout, 1, 1, 1, 0, 2.0 * M * Cout * Cin)
+            unpack(slabs, weight.shape, 1, Cout, 1, Cin, Cs, 0, Cin, 1, 1, out=dw, nslabs=ns)
+        db = None
+        if has_bias and ctx.needs_input_grad[9]:
+            with side.branch(sbias is not None, M, fork, dy):
+                if zero_bias:
+                    db = _empty((Cout,), x) if sbias is None else sbias
+                    _k("vmtl_fill_zero", p=db, n=Cout)
+                else:
+                    db = _colsum(dy, None, M, Cout, ldy, out=sbias)
+        nif = lambda g, slot: None if slot is not None else g
+        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), nif(db, sbias), None
+
+
+def bn_act_conv1x1_supported(x, act):
+    """Pointwise pre-activation node: pointwise-GEMM sized problems, activations with act(0) == 0."""
+    return (_PW and x.shape[0] * x.shape[1] * x.shape[2] <= _PW_MAX_ROWS and act in (ACT_NONE, ACT_RELU, ACT_HSWISH)
+            and os.environ.get("VMTL_BN_PW", "1") != "0")
+
+
+def bn_act_conv1x1(x, stats, rpb, bn, C, act, weight, bias=None, want_stats=True, zero_bias_grad=False):
+    """(y_raw, stats, rows_per_block) = conv1x1(act(bn(x_raw))) (+ bias); bn = the nn.BatchNorm2d container of x's layer."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
+    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, bool(want_stats), bool(zero_bias_grad))
+    y, ostats = _BNActPw.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                               weight, bias, cfg)
+    orpb = 0
+    if ostats is not None:
+        orpb = lib().raw("vmtl_conv1x1_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3], x.shape[3])
+    return y, ostats, orpb
+
+
 class _Conv1x1Cat(torch.autograd.Function):
     """(y, stats) = conv1x1(cat[xa, xb], weight) (+ bias) WITHOUT the concat (MTAN attention modules, reference
     models/mtan_model.py:57-59,139-141): the pointwise GEMM reads its K axis from two tensors, its data gradient
