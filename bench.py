@@ -85,6 +85,8 @@ def time_conv_kernels(module, batch, reps=3):
             lib().callk(name, stream=stream, **kw)
         e1.record()
         e1.synchronize()
+        if name == "vmtl_conv1x1_cat_wgrad":
+            name = "vmtl_conv2d_wgrad"
         f = fam[name if name in ("vmtl_conv2d_wgrad", "vmtl_stitch") else "vmtl_conv2d_fwd"]
         ms = e0.elapsed_time(e1) / reps
         if name == "vmtl_stitch":  # HBM-bound: flop slot carries algorithmic bytes (8 B per element)
@@ -100,6 +102,7 @@ def time_conv_kernels(module, batch, reps=3):
                 M, K, tag = kw["M"], kw["Ks"], "k1s1"
             elif "K1" in kw:
                 M, K, tag = kw["M"], kw["K1"] + kw["K2s"], "k1cat"
+                kw = dict(kw, Nw=kw.get("Nw", 0))
             elif "H2" in kw:
                 M, K, tag = 4 * kw["B"] * kw["H2"] * kw["W2"], 4 * kw["C0s"] + 9 * kw["C1s"], "up2 "
             else:

@@ -69,6 +69,9 @@ int vmtl_conv1x1_cat_fwd(const float* x, int K1, const float* x2, int K2s, const
                          float* stats, int M, int ldy, int Nw, int Cout, void* stream);
 int vmtl_conv1x1_cat_dgrad(const float* dy, const float* wp, float* dx, int N1, float* dx2, int N2s, int N2, int M,
                            int Ks, void* stream);
+/* and its weight gradient in one launch: slabs [splits][Nw][K1 + K2s], splits = vmtl_conv2d_wgrad_splits(M, Nw, K1 + K2s) */
+int vmtl_conv1x1_cat_wgrad(const float* x, int K1, const float* x2, int K2s, const float* dy, float* slabs, int splits,
+                           int M, int ldy, int Nw, void* stream);
 /* pointwise pre-activation node (the 1x1 counterpart of vmtl_conv3x3_small's prologue / vmtl_conv2d_bnbwd):
  * y = conv1x1(act(coef_a[k]*x + coef_c[k])) - BatchNorm + activation (none / relu / hardswish) of the layer that produced
  * x applied to the operand fragments, a_out (nullable [M][Ks]) = the activated matrix for the weight gradient;

@@ -702,6 +702,10 @@ struct WgradP {
   int Ktot, M;
   int chunk;        // pixels per z-slice (multiple of BP)
   int tiles_kk, tiles_co, splits;
+  // virtual concat (1x1 only): channels [0, K1) of a pixel come from x (row stride K1), [K1, Cs) from x2 (row stride
+  // Cs - K1); null = single source
+  const float* x2;
+  int K1;
 };
 
 #define BP 32
@@ -751,6 +755,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   const int dh = tap / p.KW - p.pad;
   const int dw = tap % p.KW - p.pad;
   const int hw = p.Ho * p.Wo;
+  // two-source X (1x1): this thread's channel quad lives in one of the two maps; plain global loads (the source differs
+  // between the lanes of a wave, a buffer descriptor cannot)
+  const bool two = p.x2 != nullptr;
+  const float* xsrc = two ? (ci < p.K1 ? p.x + ci : p.x2 + (ci - p.K1)) : nullptr;
+  const int xstride = two ? (ci < p.K1 ? p.K1 : p.Cs - p.K1) : 0;
 
   // per-row pixel coordinates of this thread's XP gather rows, advanced by BP pixels per chunk with
   // adds / compares only (two integer divisions per row and chunk made this kernel VALU-issue bound:
@@ -791,7 +800,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       const int h = xho[i] * p.stride + dh, w = xwo[i] * p.stride + dw;
       const bool ok = xok && m < p_end && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
       const unsigned off = ((unsigned)((xb[i] * p.H + h) * p.W + w) * (unsigned)p.Cs + (unsigned)ci) * 4u;
-      f32x4 v = bload(rs_x, ok ? off : OOB);
+      f32x4 v;
+      if (two) {
+        v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(xsrc + (size_t)((xb[i] * p.H + h) * p.W + w) * xstride);
+      } else {
+        v = bload(rs_x, ok ? off : OOB);
+      }
       rx[i] = v;
       // advance this row by BP pixels
       xwo[i] += BP;
@@ -1278,6 +1293,8 @@ static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
   return vmtl_check_launch();
 }
 
+static int wgrad_dispatch(WgradP& p, int splits, void* stream);
+
 extern "C" int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits, int B, int H, int W,
                                  int Cs, int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad,
                                  void* stream) {
@@ -1289,6 +1306,27 @@ extern "C" int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, 
   WgradP p;
   p.x = x; p.dy = dy; p.slabs = slabs; p.B = B; p.H = H; p.W = W; p.Cs = Cs; p.Ho = Ho; p.Wo = Wo; p.ldy = ldy;
   p.Nw = Nw; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.Ktot = KH * KW * Cs; p.M = B * Ho * Wo;
+  p.x2 = nullptr; p.K1 = 0;
+  return wgrad_dispatch(p, splits, stream);
+}
+
+// weight gradient of conv1x1(cat[x, x2]) (vmtl_conv1x1_cat_fwd) in one launch: slabs [splits][Nw][K1 + K2s] with
+// splits = vmtl_conv2d_wgrad_splits(M, Nw, K1 + K2s); x [M][K1] (K1 % 4 == 0), x2 [M][K2s]
+extern "C" int vmtl_conv1x1_cat_wgrad(const float* x, int K1, const float* x2, int K2s, const float* dy, float* slabs,
+                                      int splits, int M, int ldy, int Nw, void* stream) {
+  VMTL_ENTER();
+  if (!x || !x2 || !dy || !slabs || M <= 0 || K1 <= 0 || (K1 & 3) || K2s <= 0 || (K2s & 3) || (ldy & 3) || Nw <= 0 ||
+      Nw > ldy)
+    return VMTL_ERR_ARG;
+  WgradP p;
+  p.x = x; p.dy = dy; p.slabs = slabs; p.B = 1; p.H = 1; p.W = M; p.Cs = K1 + K2s; p.Ho = 1; p.Wo = M; p.ldy = ldy;
+  p.Nw = Nw; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.Ktot = p.Cs; p.M = M;
+  p.x2 = x2; p.K1 = K1;
+  return wgrad_dispatch(p, splits, stream);
+}
+
+static int wgrad_dispatch(WgradP& p, int splits, void* stream) {
+  const int Nw = p.Nw;
   if (splits != vmtl_conv2d_wgrad_splits(p.M, Nw, p.Ktot)) return VMTL_ERR_ARG;
   p.chunk = cdiv(cdiv(p.M, splits), BP) * BP;
   hipStream_t st = (hipStream_t)stream;

@@ -618,10 +618,13 @@ class _BNActPw(torch.autograd.Function):
         return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), nif(db, sbias), None
 
 
+_BN_PW_MAX_ROWS = int(os.environ.get("VMTL_BN_PW_MAX_ROWS", str(1 << 30)))
+
+
 def bn_act_conv1x1_supported(x, act):
     """Pointwise pre-activation node: pointwise-GEMM sized problems, activations with act(0) == 0."""
-    return (_PW and x.shape[0] * x.shape[1] * x.shape[2] <= _PW_MAX_ROWS and act in (ACT_NONE, ACT_RELU, ACT_HSWISH)
-            and os.environ.get("VMTL_BN_PW", "1") != "0")
+    return (_PW and x.shape[0] * x.shape[1] * x.shape[2] <= min(_PW_MAX_ROWS, _BN_PW_MAX_ROWS)
+            and act in (ACT_NONE, ACT_RELU, ACT_HSWISH) and os.environ.get("VMTL_BN_PW", "1") != "0")
 
 
 def bn_act_conv1x1(x, stats, rpb, bn, C, act, weight, bias=None, want_stats=True, zero_bias_grad=False):
@@ -690,10 +693,12 @@ class _Conv1x1Cat(torch.autograd.Function):
             with side.branch(sw is not None, M, fork, xa, xb, dy):
                 dwt = _empty(weight.shape, xa) if sw is None else sw
                 flat = dwt.view(-1)
-                sl, ns = _wgrad(xa, dy, B, H, W, Ca, H, W, ldy, Cout, 1, 1, 1, 0, 2.0 * M * Cout * Ca)
-                unpack(sl, None, 1, Cout, 1, Ca, Ca, 0, Cin, 1, 1, out=flat, nslabs=ns)
-                sl, ns = _wgrad(xb, dy, B, H, W, Cbs, H, W, ldy, Cout, 1, 1, 1, 0, 2.0 * M * Cout * Cb)
-                unpack(sl, None, 1, Cout, 1, Cb, Cbs, 0, Cin, 1, 1, out=flat[Ca:], nslabs=ns)
+                Ks = Ca + Cbs
+                ns = lib().raw("vmtl_conv2d_wgrad_splits")(M, Cout, Ks)
+                slabs = _empty((ns, Cout, Ks), xa)
+                _k("vmtl_conv1x1_cat_wgrad", _flop=2.0 * M * Cout * Cin, x=xa, K1=Ca, x2=xb, K2s=Cbs, dy=dy, slabs=slabs,
+                   splits=ns, M=M, ldy=ldy, Nw=Cout)
+                unpack(slabs, None, 1, Cout, 1, Cin, Ks, 0, Cin, 1, 1, out=flat, nslabs=ns)
             dw = None if sw is not None else dwt
         if has_bias and ctx.needs_input_grad[3]:
             with side.branch(sbias is not None, M, fork, dy):
