@@ -83,6 +83,15 @@ int vmtl_conv1x1_bn_fwd(const float* x, const float* coef_a, const float* coef_c
 int vmtl_conv1x1_bnbwd(const float* dy, const float* wp, float* dz, float* stats, const float* ez_x,
                        const float* ez_mean, const float* ez_invstd, const float* ez_gamma, const float* ez_beta,
                        int ez_act, int M, int Ks, int ldy, int Nw, int Cout, void* stream);
+/* with a residual operand: the GEMM input is a = act(coef_a*x + coef_c) + res (an inverted-residual block's bn3 output +
+ * skip connection consumed by the next block's expand conv; a_out receives a), and with a second gradient of the
+ * differentiated tensor added before the backward: dz = (dy*W + addend) * act'(...) */
+int vmtl_conv1x1_bn_res_fwd(const float* x, const float* coef_a, const float* coef_c, int act_in, const float* res,
+                            float* a_out, const float* wp, const float* bias, float* y, float* stats, int M, int Ks,
+                            int ldy, int Nw, int Cout, void* stream);
+int vmtl_conv1x1_bnbwd_add(const float* dy, const float* wp, const float* addend, float* dz, float* stats,
+                           const float* ez_x, const float* ez_mean, const float* ez_invstd, const float* ez_gamma,
+                           const float* ez_beta, int ez_act, int M, int Ks, int ldy, int Nw, int Cout, void* stream);
 
 /* vmtl_conv2d_fwd used as a DATA GRADIENT with the BatchNorm + activation backward of the layer that produced the
  * differentiated tensor fused into the epilogue (reference utils/model_utils.py:72-76 run backwards): y = conv *

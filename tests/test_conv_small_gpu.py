@@ -419,3 +419,42 @@ def test_bn_act_conv1x1_matches_torch(dev, case, training):
         assert_close(bd.grad.cpu(), br.grad, tol=2e-4, what="bn_act_conv1x1 dbias")
     assert_close(bnd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
     assert_close(bnd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 24, 12, 20, 72, True), (1, 160, 4, 8, 960, True), (2, 40, 9, 7, 120, False)])
+def test_bn_act_conv1x1_with_residual_and_returned_activation(dev, case):
+    """The inverted-residual hand-over: a = bn3(x) + res feeds the next block's expand conv (on its operand fragments),
+    comes back as a differentiable output for its other consumers, and their gradient is added inside the data gradient
+    before the BatchNorm backward: loss = <y, gy> + <a, ga> must give torch's gradients for x, res, BN and the weight."""
+    import copy
+
+    from vision_mtl_amd import ops
+
+    B, C, H, W, Cout, use_res = case
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(B, C, H, W, generator=g) * 1.1 + 0.1
+    r = torch.randn(B, C, H, W, generator=g)
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g) * 0.2
+    bnd = copy.deepcopy(bn).to(dev)
+    w = torch.randn(Cout, C, 1, 1, generator=g) / C ** 0.5
+    xr, rr, wr = x.clone().requires_grad_(True), r.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ar = bn(xr) + rr if use_res else bn(xr)
+    yr = F.conv2d(ar, wr)
+    gy, ga = torch.randn(yr.shape, generator=g), torch.randn(ar.shape, generator=g)
+    ((yr * gy).sum() + (ar * ga).sum()).backward()
+    xd, rd = to_dev_nhwc(x, dev).requires_grad_(True), to_dev_nhwc(r, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    y, stats, rpb, a = ops.bn_act_conv1x1(xd, None, 0, bnd, C, ops.ACT_NONE, wd, None, want_stats=True,
+                                          res=rd if use_res else None, return_act=True)
+    assert_close(from_dev_nhwc(a, C), ar.detach(), what="returned activation")
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="fwd")
+    ((y * to_dev_nhwc(gy, dev)).sum() + (a * to_dev_nhwc(ga, dev)).sum()).backward()
+    assert_close(from_dev_nhwc(xd.grad, C), xr.grad, tol=2e-4, what="dx")
+    if use_res:
+        assert_close(from_dev_nhwc(rd.grad, C), rr.grad, tol=2e-4, what="dres")
+    assert_close(wd.grad.cpu(), wr.grad, tol=2e-4, what="dw")
+    assert_close(bnd.weight.grad.cpu(), bn.weight.grad, tol=2e-4, what="dgamma")
+    assert_close(bnd.bias.grad.cpu(), bn.bias.grad, tol=2e-4, what="dbeta")

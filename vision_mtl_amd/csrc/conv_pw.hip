@@ -37,6 +37,7 @@ struct PwP {
   // once (workgroups of column tile 0), for the weight-gradient kernel
   const float* pa;
   const float* pc;
+  const float* res;  // nullable [M][Ks]: added after the activation (a block's residual branch: a = act(pa*x + pc) + res)
   float* a_out;
   int act_in;
   // BatchNorm-backward epilogue (ez_x != null): the launch is the data gradient of a conv whose input was
@@ -47,6 +48,7 @@ struct PwP {
   const float* ez_invstd;
   const float* ez_gamma;
   const float* ez_beta;
+  const float* ez_add;  // nullable [M][ldy]: a second gradient of the differentiated tensor, added to acc first
   int ez_act;
 };
 
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  struct Frag { f32x4 a[TM], b[TN], pa, pc; };
+  struct Frag { f32x4 a[TM], b[TN], pa, pc, r[TM]; };
   auto load = [&](int g, Frag& f) {
     const bool kok = g < G && 16 * g + 4 * lq < p.Ks;
     if (PRO) {
@@ -105,6 +107,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
     for (int i = 0; i < TM; ++i) {
       const float* src = (SRC2 && 16 * g + 4 * lq >= p.K1) ? ap2[i] : ap[i];  // K1 % 4 == 0: a quad has one source
       f.a[i] = (kok && aok[i]) ? *reinterpret_cast<const f32x4*>(src + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (PRO)
+        f.r[i] = (p.res != nullptr && kok && aok[i]) ? *reinterpret_cast<const f32x4*>(p.res + (ap[i] - p.x) + 16 * g)
+                                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
         f32x4 v = f.a[i] * f.pa + f.pc;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act_in);
+        v += f.r[i];
         f.a[i] = v;
         if (p.a_out != nullptr && tile_n == 0 && aok[i] && g < G && 16 * g + 4 * lq < p.Ks)
           *reinterpret_cast<f32x4*>(p.a_out + (size_t)(m0 + rg * 32 + 16 * i + l15) * p.Ks + 16 * g + 4 * lq) = v;
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
         if (n4 + e >= p.Cout) v[e] = 0.f;
       const int m = m0 + r;
       if (ez && m < p.M && n4 < p.ldy) {
+        if (p.ez_add != nullptr) v += *reinterpret_cast<const f32x4*>(p.ez_add + (size_t)m * p.ldy + n4);
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(p.ez_x + (size_t)m * p.ldy + n4) - e_mean) * e_is;
         const f32x4 z = e_g * xh + e_b;
 #pragma unroll
@@ -293,8 +300,8 @@ static int launch_pw(PwP& p, hipStream_t st) {
 }
 
 static void pw_plain(PwP& p) {  // no prologue, ordinary epilogue
-  p.pa = p.pc = nullptr; p.a_out = nullptr; p.act_in = 0;
-  p.ez_x = p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = nullptr; p.ez_act = 0;
+  p.pa = p.pc = p.res = nullptr; p.a_out = nullptr; p.act_in = 0;
+  p.ez_x = p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = p.ez_add = nullptr; p.ez_act = 0;
 }
 
 static int pw_dispatch(PwP& p, hipStream_t st) {
@@ -350,10 +357,9 @@ extern "C" int vmtl_conv1x1_cat_dgrad(const float* dy, const float* wp, float* d
 // conv1x1(act(coef_a[k] * x + coef_c[k])): the BatchNorm + activation of the layer that produced x (coefficients from
 // vmtl_bn_stats_coef; act in {none, relu, hardswish}: act(0) must be 0 on the pad channels) applied to the operand
 // fragments; a_out (nullable, [M][Ks]) receives the activated matrix for the weight gradient.
-extern "C" int vmtl_conv1x1_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act_in, float* a_out,
-                                   const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,
-                                   int Nw, int Cout, void* stream) {
-  VMTL_ENTER();
+static int conv1x1_bn_fwd_impl(const float* x, const float* coef_a, const float* coef_c, int act_in, const float* res,
+                               float* a_out, const float* wp, const float* bias, float* y, float* stats, int M, int Ks,
+                               int ldy, int Nw, int Cout, void* stream) {
   if (!x || !coef_a || !coef_c || !wp || !y || M <= 0 || Ks <= 0 || (Ks & 3) || ldy <= 0 || (ldy & 3)) return VMTL_ERR_ARG;
   if (Nw <= 0 || Nw > ldy || Cout <= 0 || Cout > Nw) return VMTL_ERR_ARG;
   if (act_in != VMTL_ACT_NONE && act_in != VMTL_ACT_RELU && act_in != VMTL_ACT_HSWISH) return VMTL_ERR_ARG;
@@ -361,18 +367,33 @@ extern "C" int vmtl_conv1x1_bn_fwd(const float* x, const float* coef_a, const fl
   p.x = x; p.wp = wp; p.bias = bias; p.y = y; p.stats = stats; p.M = M; p.Ks = Ks; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.x2 = nullptr; p.y2 = nullptr; p.K1 = 0; p.N1 = 0;
   pw_plain(p);
-  p.pa = coef_a; p.pc = coef_c; p.a_out = a_out; p.act_in = act_in;
+  p.pa = coef_a; p.pc = coef_c; p.res = res; p.a_out = a_out; p.act_in = act_in;
   return pw_dispatch(p, (hipStream_t)stream);
+}
+
+extern "C" int vmtl_conv1x1_bn_fwd(const float* x, const float* coef_a, const float* coef_c, int act_in, float* a_out,
+                                   const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,
+                                   int Nw, int Cout, void* stream) {
+  VMTL_ENTER();
+  return conv1x1_bn_fwd_impl(x, coef_a, coef_c, act_in, nullptr, a_out, wp, bias, y, stats, M, Ks, ldy, Nw, Cout, stream);
+}
+
+// the same with a residual operand: the GEMM's input is a = act(coef_a*x + coef_c) + res (an inverted-residual
+// block's bn3 output plus its skip connection, consumed by the next block's expand conv); a_out receives a.
+extern "C" int vmtl_conv1x1_bn_res_fwd(const float* x, const float* coef_a, const float* coef_c, int act_in,
+                                       const float* res, float* a_out, const float* wp, const float* bias, float* y,
+                                       float* stats, int M, int Ks, int ldy, int Nw, int Cout, void* stream) {
+  VMTL_ENTER();
+  if (!res) return VMTL_ERR_ARG;
+  return conv1x1_bn_fwd_impl(x, coef_a, coef_c, act_in, res, a_out, wp, bias, y, stats, M, Ks, ldy, Nw, Cout, stream);
 }
 
 // data gradient of a 1x1 conv whose input was act(BN(ez_x)), ending with that activation's and BatchNorm's backward:
 // dz [M][ldy] = (dy * W) * act'(gamma * xhat + beta), stats [vmtl_conv1x1_stats_rows(M, ldy, Ks)][2][ldy] =
 // per-row-block (sum dz, sum dz * xhat) for vmtl_bn_bwd_finalize / vmtl_bn_bwd_apply.
-extern "C" int vmtl_conv1x1_bnbwd(const float* dy, const float* wp, float* dz, float* stats, const float* ez_x,
-                                  const float* ez_mean, const float* ez_invstd, const float* ez_gamma,
-                                  const float* ez_beta, int ez_act, int M, int Ks, int ldy, int Nw, int Cout,
-                                  void* stream) {
-  VMTL_ENTER();
+static int conv1x1_bnbwd_impl(const float* dy, const float* wp, const float* addend, float* dz, float* stats,
+                              const float* ez_x, const float* ez_mean, const float* ez_invstd, const float* ez_gamma,
+                              const float* ez_beta, int ez_act, int M, int Ks, int ldy, int Nw, int Cout, void* stream) {
   if (!dy || !wp || !dz || !stats || !ez_x || !ez_mean || !ez_invstd || M <= 0 || Ks <= 0 || (Ks & 3) || ldy <= 0 ||
       (ldy & 3))
     return VMTL_ERR_ARG;
@@ -382,5 +403,27 @@ extern "C" int vmtl_conv1x1_bnbwd(const float* dy, const float* wp, float* dz, f
   p.Cout = Cout; p.x2 = nullptr; p.y2 = nullptr; p.K1 = 0; p.N1 = 0;
   pw_plain(p);
   p.ez_x = ez_x; p.ez_mean = ez_mean; p.ez_invstd = ez_invstd; p.ez_gamma = ez_gamma; p.ez_beta = ez_beta; p.ez_act = ez_act;
+  p.ez_add = addend;
   return pw_dispatch(p, (hipStream_t)stream);
+}
+
+extern "C" int vmtl_conv1x1_bnbwd(const float* dy, const float* wp, float* dz, float* stats, const float* ez_x,
+                                  const float* ez_mean, const float* ez_invstd, const float* ez_gamma,
+                                  const float* ez_beta, int ez_act, int M, int Ks, int ldy, int Nw, int Cout,
+                                  void* stream) {
+  VMTL_ENTER();
+  return conv1x1_bnbwd_impl(dy, wp, nullptr, dz, stats, ez_x, ez_mean, ez_invstd, ez_gamma, ez_beta, ez_act, M, Ks, ldy,
+                            Nw, Cout, stream);
+}
+
+// the same with a second gradient of the differentiated tensor (the block's residual / skip consumers) added to the
+// GEMM result before the activation's and BatchNorm's backward: dz = (dy*W + addend) * act'(...)
+extern "C" int vmtl_conv1x1_bnbwd_add(const float* dy, const float* wp, const float* addend, float* dz, float* stats,
+                                      const float* ez_x, const float* ez_mean, const float* ez_invstd,
+                                      const float* ez_gamma, const float* ez_beta, int ez_act, int M, int Ks, int ldy,
+                                      int Nw, int Cout, void* stream) {
+  VMTL_ENTER();
+  if (!addend) return VMTL_ERR_ARG;
+  return conv1x1_bnbwd_impl(dy, wp, addend, dz, stats, ez_x, ez_mean, ez_invstd, ez_gamma, ez_beta, ez_act, M, Ks, ldy,
+                            Nw, Cout, stream);
 }

@@ -547,14 +547,18 @@ class _BNActPw(torch.autograd.Function):
     reduce pass backward."""
 
     @staticmethod
-    def forward(ctx, x, stats, rpb, gamma, beta, rm, rv, nbt, weight, bias, cfg):
-        C, training, momentum, eps, act, want_stats, zero_bias_grad = cfg
+    def forward(ctx, x, stats, rpb, gamma, beta, rm, rv, nbt, weight, bias, res, cfg):
+        C, training, momentum, eps, act, want_stats, zero_bias_grad, return_act = cfg
         x, weight = _req(x, "x"), _req(weight, "weight")
         B, H, W, Cs = x.shape
         M = B * H * W
         Cout, Cin = weight.shape[0], weight.shape[1]
         if ceil4(C) != Cs or Cin != C or tuple(weight.shape[2:]) != (1, 1):
             raise ValueError("bn_act_conv1x1: (Cout, C, 1, 1) weight over x's channels expected")
+        if res is not None:
+            res = _req(res, "res")
+            if tuple(res.shape) != tuple(x.shape) or act != ACT_NONE:
+                raise ValueError("bn_act_conv1x1: the residual operand needs x's shape and no activation (bn3 + skip)")
         mean, invstd, ca, cc = _bn_fwd_coef(x, stats, rpb, gamma, beta, rm, rv, nbt, C, training, momentum, eps)
         wp = packs.get(weight, "fwd", (1, Cout, 1, Cin, Cs, 0, Cin, 1, 1, 0))
         ldy = ceil4(Cout)
@@ -562,23 +566,31 @@ class _BNActPw(torch.autograd.Function):
         ostats = None
         if want_stats:
             ostats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs), 2, ldy), x)
-        _k("vmtl_conv1x1_bn_fwd", _flop=2.0 * M * Cout * Cin, x=x, coef_a=ca, coef_c=cc, act_in=act, a_out=a, wp=wp, bias=bias,
-           y=y, stats=ostats, M=M, Ks=Cs, ldy=ldy, Nw=Cout, Cout=Cout)
+        if res is None:
+            _k("vmtl_conv1x1_bn_fwd", _flop=2.0 * M * Cout * Cin, x=x, coef_a=ca, coef_c=cc, act_in=act, a_out=a, wp=wp,
+               bias=bias, y=y, stats=ostats, M=M, Ks=Cs, ldy=ldy, Nw=Cout, Cout=Cout)
+        else:
+            _k("vmtl_conv1x1_bn_res_fwd", _flop=2.0 * M * Cout * Cin, x=x, coef_a=ca, coef_c=cc, act_in=act, res=res, a_out=a,
+               wp=wp, bias=bias, y=y, stats=ostats, M=M, Ks=Cs, ldy=ldy, Nw=Cout, Cout=Cout)
         ctx.save_for_backward(x, a, weight, mean, invstd, gamma, beta)
-        ctx.cfg = (C, training, act, bias is not None, bool(zero_bias_grad))
+        ctx.cfg = (C, training, act, bias is not None, bool(zero_bias_grad), res is not None)
         ctx.slots = (_slot(gamma), _slot(beta), _slot(weight), _slot(bias))
         ctx.set_materialize_grads(False)
         if ostats is not None:
             ctx.mark_non_differentiable(ostats)
+        if return_act:  # a = act(BN(x)) [+ res] as a differentiable output: the block's own skip branch / a decoder tap
+            return y, ostats, a
         return y, ostats
 
     @staticmethod
-    def backward(ctx, dy, _dstats):
+    def backward(ctx, dy, _dstats, d_a=None):
         x, a, weight, mean, invstd, gamma, beta = ctx.saved_tensors
-        C, training, act, has_bias, zero_bias = ctx.cfg
+        C, training, act, has_bias, zero_bias, has_res = ctx.cfg
         sg, sb, sw, sbias = ctx.slots
         if dy is None:
-            return (None,) * 11
+            if d_a is not None:
+                raise NotImplementedError("bn_act_conv1x1: gradient through the activation output only")
+            return (None,) * 12
         dy = _req(dy, "dy")
         B, H, W, Cs = x.shape
         M = B * H * W
@@ -592,8 +604,15 @@ class _BNActPw(torch.autograd.Function):
         dz = _empty(x.shape, x)
         rows = lib().raw("vmtl_conv1x1_stats_rows")(M, Cs, ldy)
         part = _empty((rows, 2, Cs), x)
-        _k("vmtl_conv1x1_bnbwd", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, dz=dz, stats=part, ez_x=x, ez_mean=mean,
-           ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, M=M, Ks=ldy, ldy=Cs, Nw=Cin, Cout=Cin)
+        if d_a is None:
+            _k("vmtl_conv1x1_bnbwd", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, dz=dz, stats=part, ez_x=x, ez_mean=mean,
+               ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, M=M, Ks=ldy, ldy=Cs, Nw=Cin, Cout=Cin)
+        else:  # + the gradient that reached a through its other consumers, added before act' and the reduction
+            if act != ACT_NONE:
+                raise NotImplementedError("bn_act_conv1x1: a second consumer of the activation needs act = none")
+            _k("vmtl_conv1x1_bnbwd_add", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, addend=_req(d_a, "d_a"), dz=dz, stats=part,
+               ez_x=x, ez_mean=mean, ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, M=M, Ks=ldy, ldy=Cs, Nw=Cin,
+               Cout=Cin)
         _k("vmtl_bn_bwd_finalize", partial=part, nblk=rows, M=M, C=C, Cs=Cs, sum_dz=dbeta, sum_dzx=dgamma, mean=None,
            invstd=None, gamma=None, training=1 if training else 0, coef_a=None, coef_b=None, coef_c=None)
         dx = None
@@ -615,7 +634,9 @@ class _BNActPw(torch.autograd.Function):
                 else:
                     db = _colsum(dy, None, M, Cout, ldy, out=sbias)
         nif = lambda g, slot: None if slot is not None else g
-        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), nif(db, sbias), None
+        # act = none with a residual: d(res) is the gradient w.r.t. a itself = dz (no activation derivative in it)
+        dres = dz if has_res and ctx.needs_input_grad[10] else None
+        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), nif(db, sbias), dres, None
 
 
 _BN_PW_MAX_ROWS = int(os.environ.get("VMTL_BN_PW_MAX_ROWS", str(1 << 30)))
@@ -627,17 +648,21 @@ def bn_act_conv1x1_supported(x, act):
             and act in (ACT_NONE, ACT_RELU, ACT_HSWISH) and os.environ.get("VMTL_BN_PW", "1") != "0")
 
 
-def bn_act_conv1x1(x, stats, rpb, bn, C, act, weight, bias=None, want_stats=True, zero_bias_grad=False):
-    """(y_raw, stats, rows_per_block) = conv1x1(act(bn(x_raw))) (+ bias); bn = the nn.BatchNorm2d container of x's layer."""
+def bn_act_conv1x1(x, stats, rpb, bn, C, act, weight, bias=None, want_stats=True, zero_bias_grad=False, res=None,
+                   return_act=False):
+    """(y_raw, stats, rows_per_block[, a]) = conv1x1(a) (+ bias) with a = act(bn(x_raw)) [+ res]; bn = the nn.BatchNorm2d
+    container of x's layer; res (act = none only): the skip connection added to the normalised map; return_act: also
+    hand back a (differentiable) for its other consumers (the block's own skip branch, a decoder tap)."""
     if bn.momentum is None:
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative moving average) is not implemented")
-    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, bool(want_stats), bool(zero_bias_grad))
-    y, ostats = _BNActPw.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                               weight, bias, cfg)
+    cfg = (C, bn.training, float(bn.momentum), bn.eps, act, bool(want_stats), bool(zero_bias_grad), bool(return_act))
+    out = _BNActPw.apply(x, stats, rpb, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                         weight, bias, res, cfg)
+    y, ostats = out[0], out[1]
     orpb = 0
     if ostats is not None:
         orpb = lib().raw("vmtl_conv1x1_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3], x.shape[3])
-    return y, ostats, orpb
+    return (y, ostats, orpb, out[2]) if return_act else (y, ostats, orpb)
 
 
 class _Conv1x1Cat(torch.autograd.Function):
