@@ -65,6 +65,51 @@ class BatchNormAct2d(nn.BatchNorm2d):
         self.act_code = _ACT_CODE[act]
 
 
+ENC_CHAIN = os.environ.get("VMTL_ENC_CHAIN", "1") != "0"  # blocks hand their bn3 (+ skip) to the next expand conv
+
+
+class Pending:
+    """A block output whose closing BatchNorm (bn3 / bn2 of the depthwise-separable block: no activation) and skip
+    connection have NOT been applied yet: the next layer's 1x1 conv applies them on its operand fragments
+    (ops.bn_act_conv1x1 with a residual operand) and hands the materialised map back for its other consumers (that
+    block's own skip branch, a decoder tap).  raw: the conv output, stats / rpb its BatchNorm partial rows."""
+
+    def __init__(self, raw, stats, rpb, bn, C, res):
+        self.raw, self.stats, self.rpb, self.bn, self.C, self.res = raw, stats, rpb, bn, C, res
+        self.is_tap = False  # an encoder feature: whoever materialises it leaves a handle in .act
+        self.act = None
+
+    def materialize(self) -> L.Act:
+        """Fallback: an ordinary BatchNorm (+ skip) pass."""
+        y = L.bn_act(L.Act(self.raw, self.C), self.bn, ACT_NONE, res=self.res, stats=self.stats, stats_rpb=self.rpb)
+        if self.is_tap:
+            y, self.act = L.fork(y)
+        return y
+
+    def feed_conv1x1(self, conv: nn.Conv2d, want_stats: bool):
+        """(raw output of conv, its stats, rpb, the materialised input map) with bn (+ skip) applied by conv itself."""
+        out = L.ops.bn_act_conv1x1(self.raw, self.stats, self.rpb, self.bn, self.C, ACT_NONE, conv.weight, conv.bias,
+                                   want_stats=want_stats, res=None if self.res is None else self.res.t, return_act=True)
+        raw1, st1, rpb1, a = out
+        xin = L.Act(a, self.C)
+        if self.is_tap:
+            xin, self.act = L.fork(xin)
+        return raw1, st1, rpb1, xin
+
+    def fusable_into(self, conv: nn.Conv2d) -> bool:
+        return (ENC_CHAIN and conv.groups == 1 and conv.kernel_size == (1, 1) and L._pair(conv.stride) == 1
+                and L._pair(conv.padding) == 0 and self.bn.momentum is not None
+                and L.ops.bn_act_conv1x1_supported(self.raw, ACT_NONE))
+
+
+def _close_block(y: L.Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, res):
+    """A block's closing 1x1 conv + BatchNorm (+ skip): left pending for the next layer when the chain is on."""
+    if ENC_CHAIN and bn.momentum is not None:
+        raw, st, rpb = L.conv_raw(y, conv, bn.training)
+        return Pending(raw, st, rpb, bn, conv.out_channels, res)
+    return L.conv_bn_act(y, conv, bn, ACT_NONE, res=res)
+
+
 class SqueezeExcite(nn.Module):
     """timm SqueezeExcite(gate=hard_sigmoid, act=ReLU): x * hsigmoid(W_e relu(W_r mean_hw(x) + b_r) + b_e)."""
 
@@ -98,10 +143,12 @@ class DepthwiseSeparableConv(nn.Module):
         self.bn2 = BatchNormAct2d(out_chs, None)
         self.drop_path = nn.Identity()
 
-    def run(self, x: L.Act) -> L.Act:
+    def run(self, x):
+        if isinstance(x, Pending):
+            x = x.materialize()
         x, res = L.fork(x) if self.has_skip else (x, None)
         y = L.conv_bn_act(x, self.conv_dw, self.bn1, self.bn1.act_code)
-        return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=res)
+        return _close_block(y, self.conv_pw, self.bn2, res)
 
     def run_pre(self, raw, stats, rpb, bn_in, act_in: int) -> L.Act:
         """The block on a pre-activation input: raw = the producing conv's output (with its BatchNorm partial rows),
@@ -112,7 +159,7 @@ class DepthwiseSeparableConv(nn.Module):
                                                   L._pair(dw.stride), L._pair(dw.padding),
                                                   want_stats=self.bn1.training, return_act=True)
         y = L.bn_act(L.Act(raw1, dw.out_channels), self.bn1, self.bn1.act_code, stats=st1, stats_rpb=rpb1)
-        return L.conv_bn_act(y, self.conv_pw, self.bn2, ACT_NONE, res=L.Act(a, dw.in_channels) if self.has_skip else None)
+        return _close_block(y, self.conv_pw, self.bn2, L.Act(a, dw.in_channels) if self.has_skip else None)
 
 
 class InvertedResidual(nn.Module):
@@ -129,15 +176,25 @@ class InvertedResidual(nn.Module):
         self.bn3 = BatchNormAct2d(out_chs, None)
         self.drop_path = nn.Identity()
 
-    def run(self, x: L.Act) -> L.Act:
+    def run(self, x):
         ops = L.ops
-        x, res = L.fork(x) if self.has_skip else (x, None)
-        if ops.FUSE_DW and self.bn1.act_code in (ACT_NONE, ACT_RELU, ACT_HSWISH):
-            # conv_pw -> [bn1 + act + conv_dw as one pre-activation node, bn2's statistics from its epilogue] -> bn2 + act
-            train = self.bn1.training
-            out = ops.conv2d(x.t, self.conv_pw.weight, None, 1, 0, want_stats=train)
-            raw1, st1 = out if train else (out, None)
-            rpb1 = getattr(st1, "_vmtl_rpb", 0) if st1 is not None else 0
+        fused = ops.FUSE_DW and self.bn1.act_code in (ACT_NONE, ACT_RELU, ACT_HSWISH)
+        train = self.bn1.training
+        if isinstance(x, Pending) and fused and x.fusable_into(self.conv_pw):
+            # the previous block's bn3 (+ its skip) rides on this block's expand conv; the materialised map comes back
+            # for this block's own skip branch
+            raw1, st1, rpb1, xin = x.feed_conv1x1(self.conv_pw, train)
+            res = xin if self.has_skip else None
+        else:
+            if isinstance(x, Pending):
+                x = x.materialize()
+            x, res = L.fork(x) if self.has_skip else (x, None)
+            if fused:
+                out = ops.conv2d(x.t, self.conv_pw.weight, None, 1, 0, want_stats=train)
+                raw1, st1 = out if train else (out, None)
+                rpb1 = getattr(st1, "_vmtl_rpb", 0) if st1 is not None else 0
+        if fused:
+            # [bn1 + act + conv_dw as one pre-activation node, bn2's statistics from its epilogue] -> bn2 + act
             dw = self.conv_dw
             raw2, st2, rpb2 = ops.bn_act_dwconv(raw1, st1, rpb1, self.bn1, dw.out_channels, self.bn1.act_code, dw.weight,
                                                 L._pair(dw.stride), L._pair(dw.padding), want_stats=self.bn2.training)
@@ -147,6 +204,8 @@ class InvertedResidual(nn.Module):
                 # its data gradient ends with their backward reduction
                 raw3, st3, rpb3 = ops.bn_act_conv1x1(raw2, st2, rpb2, self.bn2, dw.out_channels, self.bn2.act_code,
                                                      self.conv_pwl.weight, None, want_stats=self.bn3.training)
+                if ENC_CHAIN and self.bn3.momentum is not None:
+                    return Pending(raw3, st3, rpb3, self.bn3, self.conv_pwl.out_channels, res)
                 return L.bn_act(L.Act(raw3, self.conv_pwl.out_channels), self.bn3, ACT_NONE, res=res, stats=st3,
                                 stats_rpb=rpb3)
             y = L.bn_act(L.Act(raw2, dw.out_channels), self.bn2, self.bn2.act_code, stats=st2, stats_rpb=rpb2)
@@ -155,7 +214,7 @@ class InvertedResidual(nn.Module):
             y = L.conv_bn_act(y, self.conv_dw, self.bn2, self.bn2.act_code)
         if isinstance(self.se, SqueezeExcite):
             y = self.se.run(y)
-        return L.conv_bn_act(y, self.conv_pwl, self.bn3, ACT_NONE, res=res)
+        return _close_block(y, self.conv_pwl, self.bn3, res)
 
 
 class ConvBnAct(nn.Module):
@@ -165,7 +224,12 @@ class ConvBnAct(nn.Module):
         self.bn1 = BatchNormAct2d(out_chs, act)
         self.drop_path = nn.Identity()
 
-    def run(self, x: L.Act) -> L.Act:
+    def run(self, x):
+        if isinstance(x, Pending):
+            if x.fusable_into(self.conv):
+                raw, st, rpb, _ = x.feed_conv1x1(self.conv, self.bn1.training)
+                return L.bn_act(L.Act(raw, self.conv.out_channels), self.bn1, self.bn1.act_code, stats=st, stats_rpb=rpb)
+            x = x.materialize()
         return L.conv_bn_act(x, self.conv, self.bn1, self.bn1.act_code)
 
 
@@ -238,12 +302,15 @@ class MobileNetV3Encoder(nn.Module):
                     if fuse_stem and blk is first:
                         continue
                     y = blk.run(y)
-            if g is not groups[self._depth - 1]:  # the feature goes to the decoder AND on to the next stage
+            if g is groups[self._depth - 1]:  # the deepest feature: nothing downstream in the encoder
+                feats.append(y.materialize() if isinstance(y, Pending) else y)
+            elif isinstance(y, Pending):  # goes to the decoder AND on: the next block materialises it and leaves a handle
+                y.is_tap = True
+                feats.append(y)
+            else:
                 y, tap = L.fork(y)
                 feats.append(tap)
-            else:
-                feats.append(y)
-        return feats
+        return [f.act if isinstance(f, Pending) else f for f in feats]
 
 
 class Conv2dReLU(nn.Sequential):
