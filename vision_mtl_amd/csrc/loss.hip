@@ -61,6 +61,42 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_kernel(const float* __restr
   if (threadIdx.x == 0) partial[blockIdx.x] = bs;
 }
 
+// The same pass with the pixel's logits held in registers (C <= 32: one load per logit instead of three sweeps over
+// the channel planes for max / sum-exp / target): 44 -> ~30 us for 32x19x128x256.
+template <int Q>
+__global__ __launch_bounds__(CE_THREADS) void ce_fwd_regs_kernel(const float* __restrict__ z,
+                                                                 const long long* __restrict__ tgt,
+                                                                 double* __restrict__ partial,
+                                                                 long long* __restrict__ amax, long long P, int HW,
+                                                                 int C, long long sb, long long sc, long long sp) {
+  __shared__ double shd[4];
+  double loss = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, hw = i - b * HW;
+    const float* r = z + b * sb + hw * sp;
+    float v[4 * Q];
+#pragma unroll
+    for (int c = 0; c < 4 * Q; ++c) v[c] = c < C ? r[c * sc] : 0.f;
+    const long long t = tgt[i];
+    float m = v[0];
+    int am = 0;
+#pragma unroll
+    for (int c = 1; c < 4 * Q; ++c)
+      if (c < C && v[c] > m) { m = v[c]; am = c; }  // first maximum wins, like torch.argmax on ties
+    if (amax != nullptr) amax[i] = am;
+    float s = 0.f, zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4 * Q; ++c) {
+      if (c < C) s += expf(v[c] - m);
+      if (c == t) zt = v[c];
+    }
+    if (t < 0 || t >= C) loss += (double)__int_as_float(0x7fc00000);  // see ce_fwd_kernel
+    else loss += (double)(logf(s) - (zt - m));
+  }
+  const double bs = block_sum_d(loss, shd);
+  if (threadIdx.x == 0) partial[blockIdx.x] = bs;
+}
+
 // err (may be null): the result becomes NaN when the flag is set.
 __global__ void sum_finalize_kernel(const double* __restrict__ partial, int n, double scale, float* out,
                                     const int* __restrict__ err) {
@@ -204,8 +240,23 @@ static int ce_fwd_impl(const float* logits, const long long* target, float* loss
   const long long P = (long long)B * HW;
   const int nblk = ce_blocks(P);
   double* partial = (double*)workspace;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, amax, P, HW, C, sb,
-                     sc, sp);
+#define CEF(QV)                                                                                              \
+  hipLaunchKernelGGL((ce_fwd_regs_kernel<QV>), dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, amax, P, \
+                     HW, C, sb, sc, sp)
+  switch (C <= 32 ? (C + 3) >> 2 : 0) {
+    case 1: CEF(1); break;
+    case 2: CEF(2); break;
+    case 3: CEF(3); break;
+    case 4: CEF(4); break;
+    case 5: CEF(5); break;
+    case 6: CEF(6); break;
+    case 7: CEF(7); break;
+    case 8: CEF(8); break;
+    default:
+      hipLaunchKernelGGL(ce_fwd_kernel, dim3(nblk), dim3(CE_THREADS), 0, st, logits, target, partial, amax, P, HW, C, sb,
+                         sc, sp);
+  }
+#undef CEF
   hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, 1.0 / (double)P, loss,
                      (const int*)nullptr);
   return vmtl_check_launch();
