@@ -1172,7 +1172,11 @@ static int up2_pick_tile(int Mq, int ncols) {
     const int id = atoi(f);
     if (id >= 0 && id < VMTL_NTILES) return id;
   }
-  const int big = pick_from(kBigIds, VMTL_NBIG, ncols);
+  int big = pick_from(kBigIds, VMTL_NBIG, ncols);
+  // 65-68 columns: the phase convs run faster on five MFMA column fragments (80 columns, 12 idle) than on four plus
+  // four VALU tail columns - measured 364 vs 392 us on the 135+16 -> 67 layer (tools/bench_up2.py); the plain 3x3
+  // layers of that width prefer the tail (241 vs 263 us, tools/bench_conv.py)
+  if (big == 14) big = 3;
   if ((long long)cdiv(Mq, 128) * 4 * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
   if (conv_bf16x3() && kTiles[big].bn >= 80) return pick_from(kSmallIds, 4, ncols);
   return big;
