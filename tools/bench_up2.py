@@ -21,7 +21,7 @@ for name, B, H2, W2, C0, C1, Cout in [("block5 conv1 67->33", 32, 64, 128, 67, 0
     y = torch.empty(B, 2 * H2, 2 * W2, ldy, device=dev)
     bm = L.raw("vmtl_conv2d_up2_stats_block")(B, H2, W2, ldy)
     M = B * H2 * W2
-    stats = torch.empty(4 * (M // bm), 2, ldy, device=dev) if M % bm == 0 else None
+    stats = torch.empty(4 * (M // bm), 2, ldy, device=dev) if M % bm == 0 and not os.environ.get("UP2_NO_STATS") else None
     fn = lambda: L.callk("vmtl_conv2d_up2_fwd", xl=xl, skip=skip, wp_eff=wp, y=y, stats=stats, B=B, H2=H2, W2=W2, C0s=C0s,
                          C1s=C1s, ldy=ldy, Cout=Cout, stream=st)
     fn()

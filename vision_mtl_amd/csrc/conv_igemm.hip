@@ -589,7 +589,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       }
     }
   } else if (p.stats != nullptr) {
-    float* red = smem;  // [2][WAVES_M][BN]; the staging tiles are dead after the last barrier
+    // per-tile (mean, M2) of every column in ONE pass and one barrier: every wave sums d = v - pivot and d*d over its
+    // TM*16 rows, pivot = the column's value in the wave's first row (shifted sums: accurate when |mean| >> std);
+    // the WAVES_M waves of a column are merged with Chan's formula.  (Two passes - mean, then squared deviations -
+    // with a barrier each cost 57 of the 466 us of the 67 -> 33 full-resolution UP2 conv: tools/bench_up2.py.)
+    float* red = smem;  // [3][WAVES_M][BN]: sum d, sum d*d, pivot; the staging tiles are dead after the last barrier
     const int nvalid = min(BM, p.M - m0);
     auto colval = [&](int i, int j, int r, float& v) -> bool {
       const int m = m0 + (wm * TM + i) * 16 + 4 * lq + r;
@@ -599,84 +603,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     };
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float s1 = 0.f;
+      float v0;
+      colval(0, j, 0, v0);
+      const float pv = __shfl(v0, l15, 64);  // lane l15 (lq = 0) holds row 0 of the wave's rows for this column
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v;
-          if (colval(i, j, r, v)) s1 += v;
+          if (colval(i, j, r, v)) {
+            const float d = v - pv;
+            s1 += d;
+            s2 += d * d;
+          }
         }
       s1 += __shfl_xor(s1, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
-      if (lq == 0) red[wm * BN + (wn * TN + j) * 16 + l15] = s1;
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lq == 0) {
+        const int c = (wn * TN + j) * 16 + l15;
+        red[(0 * WAVES_M + wm) * BN + c] = s1;
+        red[(1 * WAVES_M + wm) * BN + c] = s2;
+        red[(2 * WAVES_M + wm) * BN + c] = pv;
+      }
     }
     if (NT > 0) {  // tail columns: lanes of quarter 0 hold one row each -> fold the 16 rows of the tile
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        float s1 = 0.f;
+        const float pv = __shfl(tv[0][t], 0, 64);
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          if (m0 + (wm * TM + i) * 16 + l15 < p.M) s1 += tv[i][t];
-        s1 += __shfl_xor(s1, 1, 64);
-        s1 += __shfl_xor(s1, 2, 64);
-        s1 += __shfl_xor(s1, 4, 64);
-        s1 += __shfl_xor(s1, 8, 64);
-        if (lane == 0) red[wm * BN + BNM + t] = s1;
-      }
-    }
-    __syncthreads();
-    float mean[TN];
+          if (m0 + (wm * TM + i) * 16 + l15 < p.M) {
+            const float d = tv[i][t] - pv;
+            s1 += d;
+            s2 += d * d;
+          }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + (wn * TN + j) * 16 + l15];
-      mean[j] = s / (float)nvalid;
-    }
-    if (NT > 0) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_M; ++w) s += red[w * BN + BNM + t];
-        const float mt = s / (float)nvalid;
-        float s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          if (m0 + (wm * TM + i) * 16 + l15 < p.M) s2 += (tv[i][t] - mt) * (tv[i][t] - mt);
-        s2 += __shfl_xor(s2, 1, 64);
-        s2 += __shfl_xor(s2, 2, 64);
-        s2 += __shfl_xor(s2, 4, 64);
-        s2 += __shfl_xor(s2, 8, 64);
-        if (lane == 0) red[(WAVES_M + wm) * BN + BNM + t] = s2;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v;
-          if (colval(i, j, r, v)) s2 += (v - mean[j]) * (v - mean[j]);
+        for (int o = 1; o < 16; o <<= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
         }
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (lq == 0) red[(WAVES_M + wm) * BN + (wn * TN + j) * 16 + l15] = s2;
+        if (lane == 0) {
+          red[(0 * WAVES_M + wm) * BN + BNM + t] = s1;
+          red[(1 * WAVES_M + wm) * BN + BNM + t] = s2;
+          red[(2 * WAVES_M + wm) * BN + BNM + t] = pv;
+        }
+      }
     }
     __syncthreads();
     for (int c = tid; c < BN; c += 256) {
-      float s = 0.f, m2 = 0.f;
+      float cn = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WAVES_M; ++w) {
-        s += red[w * BN + c];
-        m2 += red[(WAVES_M + w) * BN + c];
+        const float nw = (float)max(0, min(TM * 16, nvalid - w * TM * 16));  // valid rows of wave w
+        if (nw > 0.f) {
+          const float s1 = red[(0 * WAVES_M + w) * BN + c], s2 = red[(1 * WAVES_M + w) * BN + c];
+          const float mw = red[(2 * WAVES_M + w) * BN + c] + s1 / nw;
+          const float qw = s2 - s1 * s1 / nw;
+          const float tot = cn + nw, d = mw - mean;
+          mean += d * (nw / tot);
+          m2 += qw + d * d * (cn * nw / tot);
+          cn = tot;
+        }
       }
       const int n = n0 + c;
       if (n < p.ldy) {
-        p.stats[((size_t)tile_m * 2 + 0) * p.ldy + n] = s / (float)nvalid;
+        p.stats[((size_t)tile_m * 2 + 0) * p.ldy + n] = mean;
         p.stats[((size_t)tile_m * 2 + 1) * p.ldy + n] = m2;
       }
     }
