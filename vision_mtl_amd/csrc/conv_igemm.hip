@@ -206,21 +206,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
   };
 
+  // UP2: which gather segment(s) a BK chunk touches is wave-uniform (kchunk is a scalar).  Branching on it keeps the
+  // buffer descriptor of each load uniform instead of a per-lane select between the two tensors (the lanes disagree
+  // only in the one chunk that straddles the boundary): 437 -> 420 us on the 67 -> 33 layer (tools/bench_up2.py).
+  int kchunk = 0;
+  auto load_a_seg0 = [&](int i, bool kok) {
+    const int h = hb[i] + dh, w = wb[i] + dw;
+    const bool ok = kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+    const unsigned off = ((unsigned)(pixbase[i] + h * p.W + w) * (unsigned)p.Cs + (unsigned)ci) * 4u;
+    ra[i] = bload(rs_x, ok ? off : OOB);
+  };
+  auto load_a_seg1 = [&](int i, bool kok) {
+    // full-res skip: output pixel (2*h2 + pa, 2*w2 + pb), tap offset dh-1 / dw-1; hb = h2 - 1 + pa
+    const int h = 2 * hb[i] + 1 - pa + dh, w = 2 * wb[i] + 1 - pb + dw;
+    const bool ok = kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W);
+    const unsigned off = ((unsigned)(4 * pixbase[i] + h * (2 * p.W) + w) * (unsigned)p.C2s + (unsigned)ci) * 4u;
+    ra[i] = bload(rs_x2, ok ? off : OOB);
+  };
   auto load_tile = [&]() {
     const bool kok = kk < p.Ktot;
+    const int seg_end = 4 * p.Cs;  // first K index of segment 1
+    if (!UP2 || kchunk + BK <= seg_end || p.C2s == 0) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      if (!UP2 || seg == 0) {
-        const int h = hb[i] + dh, w = wb[i] + dw;
-        const bool ok = kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-        const unsigned off = ((unsigned)(pixbase[i] + h * p.W + w) * (unsigned)p.Cs + (unsigned)ci) * 4u;
-        ra[i] = bload(rs_x, ok ? off : OOB);
-      } else {
-        // full-res skip: output pixel (2*h2 + pa, 2*w2 + pb), tap offset dh-1 / dw-1; hb = h2 - 1 + pa
-        const int h = 2 * hb[i] + 1 - pa + dh, w = 2 * wb[i] + 1 - pb + dw;
-        const bool ok = kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W);
-        const unsigned off = ((unsigned)(4 * pixbase[i] + h * (2 * p.W) + w) * (unsigned)p.C2s + (unsigned)ci) * 4u;
-        ra[i] = bload(rs_x2, ok ? off : OOB);
+      for (int i = 0; i < RA; ++i) load_a_seg0(i, kok && (!UP2 || seg == 0));
+    } else if (kchunk >= seg_end) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) load_a_seg1(i, kok);
+    } else {  // the chunk straddling the boundary: per lane
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        if (seg == 0) load_a_seg0(i, kok);
+        else load_a_seg1(i, kok);
       }
     }
 #pragma unroll
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       const bool ok = kok && n < p.Nw && r0 + 32 * i < BN;
       rb[i] = bload(rs_w, ok ? ((unsigned)n * (unsigned)p.Ktot + (unsigned)kk) * 4u : OOB);
     }
+    kchunk += BK;
     // advance to the next BK chunk
     kk += BK;
     ci += BK;
@@ -296,6 +313,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     nk = min(nk - k_begin, p.ksteps_per_split);
     kk += k_begin * BK;
     ci += k_begin * BK;
+    kchunk += k_begin * BK;
     normalize();
   }
   // tail columns that hold real weight rows (the others multiply zeros): wave-uniform
