@@ -210,41 +210,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // buffer descriptor of each load uniform instead of a per-lane select between the two tensors (the lanes disagree
   // only in the one chunk that straddles the boundary): 437 -> 420 us on the 67 -> 33 layer (tools/bench_up2.py).
   int kchunk = 0;
-  auto load_a_seg0 = [&](int i, bool kok) {
+  // byte offset of a gathered element = row part (fixed per thread row, computed once) + tap part (one per chunk):
+  // ((pix + h*W + w)*Cs + ci)*4 with h = hb + dh, w = wb + dw splits into (pix + hb*W + wb)*Cs*4 + ((dh*W + dw)*Cs + ci)*4
+  // (mod 2^32; in-range elements never wrap) - 2 integer multiplies per chunk instead of 2 per row and chunk
+  // (v_mul_lo_u32 is quarter rate: they were 8 of the ~40 VALU instructions per MFMA-free slot of the narrow tiles)
+  unsigned rowb0[RA], rowb1[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    rowb0[i] = (unsigned)(pixbase[i] + hb[i] * p.W + wb[i]) * (unsigned)p.Cs * 4u;
+    rowb1[i] = UP2 ? (unsigned)(4 * pixbase[i] + (2 * hb[i] + 1 - pa) * (2 * p.W) + (2 * wb[i] + 1 - pb)) *
+                         (unsigned)p.C2s * 4u
+                   : 0u;
+  }
+  unsigned wrowb[RB];  // weight rows likewise: n * Ktot * 4 once
+  bool wrow_ok[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    wrow_ok[i] = n < p.Nw && r0 + 32 * i < BN;
+    wrowb[i] = (unsigned)n * (unsigned)p.Ktot * 4u;
+  }
+  auto load_a_seg0 = [&](int i, bool kok, unsigned tapb) {
     const int h = hb[i] + dh, w = wb[i] + dw;
     const bool ok = kok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-    const unsigned off = ((unsigned)(pixbase[i] + h * p.W + w) * (unsigned)p.Cs + (unsigned)ci) * 4u;
-    ra[i] = bload(rs_x, ok ? off : OOB);
+    ra[i] = bload(rs_x, ok ? rowb0[i] + tapb : OOB);
   };
-  auto load_a_seg1 = [&](int i, bool kok) {
+  auto load_a_seg1 = [&](int i, bool kok, unsigned tapb) {
     // full-res skip: output pixel (2*h2 + pa, 2*w2 + pb), tap offset dh-1 / dw-1; hb = h2 - 1 + pa
     const int h = 2 * hb[i] + 1 - pa + dh, w = 2 * wb[i] + 1 - pb + dw;
     const bool ok = kok && (unsigned)h < (unsigned)(2 * p.H) && (unsigned)w < (unsigned)(2 * p.W);
-    const unsigned off = ((unsigned)(4 * pixbase[i] + h * (2 * p.W) + w) * (unsigned)p.C2s + (unsigned)ci) * 4u;
-    ra[i] = bload(rs_x2, ok ? off : OOB);
+    ra[i] = bload(rs_x2, ok ? rowb1[i] + tapb : OOB);
   };
   auto load_tile = [&]() {
     const bool kok = kk < p.Ktot;
     const int seg_end = 4 * p.Cs;  // first K index of segment 1
+    const unsigned tap0 = ((unsigned)(dh * p.W + dw) * (unsigned)p.Cs + (unsigned)ci) * 4u;
     if (!UP2 || kchunk + BK <= seg_end || p.C2s == 0) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) load_a_seg0(i, kok && (!UP2 || seg == 0));
-    } else if (kchunk >= seg_end) {
+      for (int i = 0; i < RA; ++i) load_a_seg0(i, kok && (!UP2 || seg == 0), tap0);
+    } else {
+      const unsigned tap1 = ((unsigned)(dh * (2 * p.W) + dw) * (unsigned)p.C2s + (unsigned)ci) * 4u;
+      if (kchunk >= seg_end) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) load_a_seg1(i, kok);
-    } else {  // the chunk straddling the boundary: per lane
+        for (int i = 0; i < RA; ++i) load_a_seg1(i, kok, tap1);
+      } else {  // the chunk straddling the boundary: per lane
 #pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        if (seg == 0) load_a_seg0(i, kok);
-        else load_a_seg1(i, kok);
+        for (int i = 0; i < RA; ++i) {
+          if (seg == 0) load_a_seg0(i, kok, tap0);
+          else load_a_seg1(i, kok, tap1);
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int n = n0 + r0 + 32 * i;
-      const bool ok = kok && n < p.Nw && r0 + 32 * i < BN;
-      rb[i] = bload(rs_w, ok ? ((unsigned)n * (unsigned)p.Ktot + (unsigned)kk) * 4u : OOB);
-    }
+    for (int i = 0; i < RB; ++i) rb[i] = bload(rs_w, (kok && wrow_ok[i]) ? wrowb[i] + (unsigned)kk * 4u : OOB);
     kchunk += BK;
     // advance to the next BK chunk
     kk += BK;
