@@ -239,26 +239,38 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
       *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = c;
     }
   } else if (p.stats != nullptr) {
-    // per-tile (mean, M2) of every column: rows of a column live in the RPP threads tid = q + Q * r0
+    // per-tile (mean, M2) of every column in one reduction round: sums of d = v - pivot and d*d, pivot = the column's
+    // value in the tile's first row (still in the LDS tile: shifted sums stay accurate when |mean| >> std).  Rows of a
+    // column live in the RPP threads tid = q + Q * r0.
     const int nvalid = min(BM, p.M - m0);
-    red[0][tid] = s1;
-    __syncthreads();
-    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pv = *reinterpret_cast<const f32x4*>(&tile[0][0][4 * q]);
 #pragma unroll
-    for (int k = 0; k < RPP; ++k) m += red[0][q + Q * k];
-    m *= 1.f / (float)nvalid;
-    f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 1; k < KW; ++k) pv += *reinterpret_cast<const f32x4*>(&tile[k][0][4 * q]);
+    pv += bias4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n4 + e >= p.Cout) pv[e] = 0.f;
+    f32x4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = d1;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps)
-      if (r0 + ps * RPP < BM && m0 + r0 + ps * RPP < p.M) s2 += (val[ps] - m) * (val[ps] - m);
-    red[1][tid] = s2;
+      if (r0 + ps * RPP < BM && m0 + r0 + ps * RPP < p.M) {
+        const f32x4 d = val[ps] - pv;
+        d1 += d;
+        d2 += d * d;
+      }
+    red[0][tid] = d1;
+    red[1][tid] = d2;
     __syncthreads();
-    if (tid < Q && n4 < p.ldy) {
-      f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    if (tid < Q && n4 < p.ldy) {  // r0 == 0: q == tid
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
 #pragma unroll
-      for (int k = 0; k < RPP; ++k) c += red[1][tid + Q * k];
-      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = m;  // r0 == 0: q == tid
-      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = c;
+      for (int k = 0; k < RPP; ++k) {
+        a += red[0][tid + Q * k];
+        c += red[1][tid + Q * k];
+      }
+      const float inv = 1.f / (float)nvalid;
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = pv + a * inv;
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = c - a * a * inv;
     }
   }
   (void)cnt;
