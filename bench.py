@@ -3,9 +3,17 @@
 (model forward -> CrossEntropy + SILog -> backward to every parameter [+ one RCCL gradient
 all-reduce when N > 1]) on synthetic data, fp32, model in train mode — BASELINE.json's metric.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Besides the driver contract it carries
+N > 1 runs one process per GPU over RCCL: either the driver starts the ranks itself (python -m torch.distributed.run
+... bench.py --gpus N, WORLD_SIZE set) or - plain `python bench.py --gpus N` - this process starts them: before anything
+touches the GPU it spawns N fresh child ranks through torch.distributed.run, relays rank 0's JSON line and exits with
+the children's status (the parent never initialises HIP and nothing that has is ever re-executed).
+
+Prints ONE JSON line on rank 0.  The step is the PRODUCT's captured step (vision_mtl_amd.graphed.GraphedStep: fwd + CE +
+SILog + bwd replayed from a hipGraph); config.ms_per_step_eager is the same step issued launch by launch from Python,
+the way the reference's loop drives it.  config.backend / ranks_seen / loss_per_rank prove that N ranks took part.
+Besides the driver contract the line carries
   roofline     : the forward + data-gradient conv launches of one step (conv_igemm_kernel and its two
                  specialisations conv3x3_small_kernel / pw_gemm_kernel) timed launch-by-launch with HIP
                  events on the launch stream; achieved = algorithmic FLOPs per launch / average launch
@@ -47,7 +55,7 @@ def build(args, device):
     from vision_mtl_amd.utils.pipeline_utils import build_model
 
     torch.manual_seed(11)  # reference cfg.py:194
-    ns = argparse.Namespace(model_name=args.model, backbone_weights=None, channel_wise_stitching=True)
+    ns = argparse.Namespace(model_name=args.model, backbone_weights=None, channel_wise_stitching=args.stitch == "channel")
     model = build_model(ns, argparse.Namespace(num_classes=args.classes)).to(device).train()
     module = MTLModule(model, num_classes=args.classes, device=str(device))
     module.compute_metrics = False  # the metric is fwd + losses + bwd ("no metrics, no logging")
@@ -125,7 +133,7 @@ def cpu_baseline(args):
     from vision_mtl_amd.utils.pipeline_utils import build_model
 
     torch.manual_seed(11)
-    ns = argparse.Namespace(model_name=args.model, backbone_weights=None, channel_wise_stitching=True)
+    ns = argparse.Namespace(model_name=args.model, backbone_weights=None, channel_wise_stitching=args.stitch == "channel")
     sd = build_model(ns, argparse.Namespace(num_classes=args.classes)).state_dict()
     sd = {k: v.clone() for k, v in sd.items()}
     for k, v in sd.items():
@@ -203,28 +211,33 @@ def measure(args, device, rank, world, extras=False):
         torch.cuda.synchronize()
         log(f"eager warm-up step {i} done")
 
+    # the same step driven the way the reference's loop drives it (training_lit.py:81-98): launch by launch from Python
+    ms_eager = None
+    if True:
+        n = 5
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            step()
+            after_step()
+        torch.cuda.synchronize()
+        ms_eager = (time.perf_counter() - t1) / n * 1e3
+        module.step_outputs["train"]["loss"].clear()
+        log(f"eager: {ms_eager:.2f} ms/step")
+
     if os.environ.get("VMTL_STAMPS") == "1":  # two-stream timeline of one replayed step (tuning aid)
         ops._STAMPS = []
-    graph = None
+    gstep = None
     if not args.no_graph:
-        global _REHEARSAL_STREAM
-        if _REHEARSAL_STREAM is None:  # one per process: HIP maps streams onto few hardware queues round-robin
-            _REHEARSAL_STREAM = torch.cuda.Stream()
-        side = _REHEARSAL_STREAM
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        for k in module.step_outputs["train"]:
-            module.step_outputs["train"][k].clear()
-        log("hipGraph captured")
+        from vision_mtl_amd.graphed import GraphedStep
+
+        gstep = GraphedStep(module, batch, arena=arena, warmup=1)  # the PRODUCT's captured step (fwd + losses + bwd)
+        log("hipGraph captured (vision_mtl_amd.graphed.GraphedStep)")
+    graph = gstep.graph if gstep is not None else None
 
     def run_step():
         if graph is not None:
-            graph.replay()
+            graph.replay()  # the batch is already resident in the step's static input buffers (metric: inputs in HBM)
         else:
             step()
         after_step()
@@ -247,14 +260,25 @@ def measure(args, device, rank, world, extras=False):
         dt = float(t.item())
     if ops._STAMPS is not None and graph is not None:
         stamps, ops._STAMPS = ops._STAMPS, None
-        n = len(stamps) // 2  # the pre-capture rehearsal step and the captured step both appended
+        n = len(stamps) // 3  # GraphedStep's warm-up step, its rehearsal step and the captured step all appended
         graph.replay()
         torch.cuda.synchronize()
         vals = [(int(t.item()), tag) for tag, t in stamps[-n:]]
         t0 = min(v for v, _ in vals)
         for v, tag in sorted(vals):
             log(f"stamp {(v - t0) / 100.0:10.1f} us  {tag}")
-    loss_val = float((static_loss if graph is not None else step()).item())
+    loss_t = (gstep._loss if gstep is not None else step().detach()).reshape(1).float()
+    loss_val = float(loss_t.item())
+    # proof that `world` ranks took part: every rank contributes a one and its loss (each rank has its own shard)
+    ranks_seen, losses, backend = 1, [round(loss_val, 5)], "none"
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
+        gathered = [torch.zeros_like(loss_t) for _ in range(world)]
+        dist.all_gather(gathered, loss_t)
+        losses = [round(float(g.item()), 5) for g in gathered]
+        backend = dist.get_backend()
     log(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     # "report Adam-inclusive step time separately" - the same steps followed by the fused Adam
     # update over the flat arena (one launch); measured after the headline so it cannot touch `value`
@@ -286,10 +310,16 @@ def measure(args, device, rank, world, extras=False):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model} {args.height}x{args.width} C={args.classes} bs={args.batch}/GPU, "
                                f"train-mode fwd + CE + SILog + bwd" + (" + Adam" if args.adam else "")
-                               + (" + 1 RCCL grad all-reduce" if world > 1 else ""),
+                               + (f" + 1 grad all-reduce ({'RCCL' if backend == 'nccl' else backend})" if world > 1 else ""),
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "launch": "eager" if graph is None else "hipGraph replay", "loss": round(loss_val, 5)},
+                   "launch": "eager" if graph is None else "hipGraph replay (vision_mtl_amd.graphed.GraphedStep)",
+                   "loss": round(loss_val, 5), "backend": backend, "ranks_seen": ranks_seen, "loss_per_rank": losses},
     }
+    if args.model == "csnet":
+        out["config"]["workload"] += f", {args.stitch}-wise stitching"
+        out["config"]["channel_wise_stitching"] = args.stitch == "channel"
+    if ms_eager is not None:
+        out["config"]["ms_per_step_eager"] = round(ms_eager, 3)
     if ms_adam is not None:
         out["config"]["ms_per_step_with_adam"] = round(ms_adam, 4)
     gf = STEP_GFLOP_PER_IMG.get((args.model, args.height, args.width))
@@ -321,7 +351,11 @@ def measure(args, device, rank, world, extras=False):
         # committed rocprofv3 --pmc summary of this same workload is quoted (profiles/, tools/profile_configs.sh)
         tag = {("basic", 128, 256, 32): "basic", ("basic", 128, 256, 8): "basic_bs8", ("basic", 256, 256, 32): "basic_256",
                ("csnet", 128, 256, 32): "csnet", ("mtan", 256, 256, 16): "mtan"}.get((args.model, args.height, args.width, args.batch))
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_{tag}_pmc.json")
+        if tag == "csnet" and args.stitch == "layer":
+            tag = "csnet_layer"
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        pmc = next((os.path.join(prof, f"{r}_{tag}_pmc.json") for r in ("r03", "r02")
+                    if tag and os.path.exists(os.path.join(prof, f"{r}_{tag}_pmc.json"))), "")
         if tag and os.path.exists(pmc):
             with open(pmc) as f:
                 ks = json.load(f)["kernels"]
@@ -329,8 +363,9 @@ def measure(args, device, rank, world, extras=False):
             if fams:
                 tot = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in fams)
                 out["roofline"]["traffic"] = round(tot / sum(k["launches"] for k in fams))
-                out["roofline"]["traffic_unit"] = ("HBM bytes per launch over the same kernels (rocprofv3 --pmc FETCH_SIZE x2 + "
-                                                   f"WRITE_SIZE, profiles/r02_{tag}_pmc.json)")
+                out["roofline"]["traffic_unit"] = "HBM bytes per launch over the same kernels (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                # NOT measured in this run: counters cannot be collected from inside the process
+                out["roofline"]["traffic_source"] = f"committed profile profiles/{os.path.basename(pmc)}"
         wg = fam["vmtl_conv2d_wgrad"]
         if wg["ms"] > 0:
             wach = wg["flop"] / (wg["ms"] * 1e-3) / 1e12
@@ -348,7 +383,7 @@ def measure(args, device, rank, world, extras=False):
     if world == 1 and extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     # drop this configuration's device state before the next one is built
-    del graph, arena, module, model, batch
+    del graph, gstep, arena, module, model, batch
     ops.packs.refresh()
     torch.cuda.empty_cache()
     return out
@@ -359,8 +394,28 @@ _REHEARSAL_STREAM = None
 
 EXTRA_CONFIGS = [dict(model="basic", batch=8, height=128, width=256, classes=19),    # the metric string's literal bs=8
                  dict(model="basic", batch=32, height=256, width=256, classes=19),   # north_star: "and 256x256 batches"
-                 dict(model="csnet", batch=32, height=128, width=256, classes=19),   # configs[2]
+                 # configs[2], both stitch modes (the reference CLI default is layer-wise, utils/utils.py:27)
+                 dict(model="csnet", batch=32, height=128, width=256, classes=19, stitch="layer"),
+                 dict(model="csnet", batch=32, height=128, width=256, classes=19, stitch="channel"),
                  dict(model="mtan", batch=16, height=256, width=256, classes=14)]    # configs[3]
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start N fresh ranks (one process per
+    GPU) and relay their output.  Runs BEFORE anything in this process touches the GPU; the parent only waits."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log(f"spawning {n} ranks: {' '.join(cmd)}")
+    proc = subprocess.run(cmd, env=env)  # stdout / stderr are inherited: rank 0's JSON line goes straight through
+    return proc.returncode
 
 
 def main():
@@ -373,31 +428,57 @@ def main():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--classes", type=int, default=19)
+    ap.add_argument("--stitch", default="layer", choices=["layer", "channel"],
+                    help="csnet: --channel_wise_stitching of the reference CLI (default off = layer-wise, utils/utils.py:27)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--adam", action="store_true", help="include the fused Adam update in the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--only-headline", action="store_true", help="skip the `configs` array of the other BASELINE configurations")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="only the multi-rank plumbing (rendezvous, one all-reduce, rank 0's JSON line): runs on CPU over gloo")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))  # nothing above this line touches the GPU
+
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:  # checked BEFORE the rendezvous (which would wait for the others)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: launch with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}, or drop the WORLD_SIZE variable")
     from vision_mtl_amd import dp
 
     rank, world, local_rank = dp.init_distributed()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launcher_selftest:
+        import torch.distributed as dist
+
+        ones = torch.ones(1, device="cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(ones)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "ranks_seen": int(ones.item()),
+                              "backend": dist.get_backend() if world > 1 else "none"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(device)}; building {args.model}")
     out = measure(args, device, rank, world, extras=True)
     default_headline = (args.model, args.batch, args.height, args.width) == ("basic", 32, 128, 256)
-    if rank == 0 and world == 1 and default_headline and not args.only_headline and not args.no_graph:
-        # driver-visible lines for the other BASELINE.json configurations (same measurement, fewer steps)
-        out["configs"] = []
+    if default_headline and not args.only_headline and not args.no_graph:
+        # driver-visible lines for the other BASELINE.json configurations (same measurement, fewer steps).  At N > 1 every
+        # rank runs them too (north_star: 128x256 and 256x256 batches at 1/2/4/8 GPUs), without the per-launch roofline
+        if rank == 0:
+            out["configs"] = []
         for c in EXTRA_CONFIGS:
-            a = argparse.Namespace(**{**vars(args), **c, "steps": min(args.steps, 10), "warmup": min(args.warmup, 3)})
+            a = argparse.Namespace(**{**vars(args), **c, "steps": min(args.steps, 10), "warmup": min(args.warmup, 3),
+                                      "no_roofline": args.no_roofline or world > 1})
             r = measure(a, device, rank, world)
-            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in r}
+            if rank != 0:
+                continue
+            keep = {k: r[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "dtype") if k in r}
             keep["config"] = r["config"]
             if "roofline" in r:
                 keep["roofline"] = r["roofline"]

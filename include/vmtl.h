@@ -31,6 +31,9 @@ extern "C" {
 const char* vmtl_version(void);
 /* HIP's text for the last launch failure (status -2) seen on the calling thread */
 const char* vmtl_last_error_string(void);
+/* The VMTL_* tuning overrides (VMTL_FORCE_TILE, VMTL_BF16X3, ...) are read from the environment once and cached;
+ * this makes the next use re-read them.  Returns the new epoch. */
+int vmtl_reload_env(void);
 /* tuning aid: *out = 100 MHz device wall clock at the moment `stream` gets there */
 int vmtl_timestamp(long long* out, void* stream);
 
@@ -270,6 +273,9 @@ int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, float* dx, 
                     int C, int Cs, int wstride, int reduce_all, void* stream);
 /* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */
 int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream);
+/* y = a + b (+ c) (+ d), c / d nullable, total % 4 == 0: the gradient sum of an activation with 2..4 consumers - what
+ * autograd's AccumulateGrad / add nodes do for x, d, merged in models/mtan_model.py:364-399 and every residual branch */
+int vmtl_add_n(const float* a, const float* b, const float* c, const float* d, float* y, long long total, void* stream);
 /* y = wa*a + wb*b: the weighted sum of the task losses (lit_module.py:127-129) */
 int vmtl_axpby(const float* a, const float* b, float* y, float wa, float wb, long long total, void* stream);
 int vmtl_fill_zero(float* p, long long n, void* stream); /* n floats <- 0 (a memset node) */

@@ -19,3 +19,18 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def vmtl_env(monkeypatch):
+    """set(name, value): set a VMTL_* tuning override for this test.  The library caches them after the first read
+    (no getenv on the launch path), so every change is followed by vmtl_reload_env() - also when the test ends."""
+    from vision_mtl_amd._lib import lib
+
+    def set_(name, value):
+        monkeypatch.setenv(name, str(value))
+        lib().raw("vmtl_reload_env")()
+
+    yield set_
+    monkeypatch.undo()
+    lib().raw("vmtl_reload_env")()

@@ -93,3 +93,27 @@ def test_shard_batch_rejects_ragged():
 
     with pytest.raises(ValueError):
         dp.shard_batch({"img": torch.zeros(5, 3, 4, 4)}, 0, 2)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment: the process spawns 2 fresh ranks before
+    touching any GPU, the ranks rendezvous (gloo here: no GPU in this container), all-reduce once, and rank 0's JSON line
+    comes back through the parent together with the children's exit status."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "gloo"
+    # a failing rank's status reaches the caller (here: --gpus disagrees with the world torch.distributed.run builds)
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0

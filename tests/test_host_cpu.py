@@ -209,12 +209,26 @@ def test_prepare_sample_and_collate_follow_the_reference_contract():
     assert s["mask"].dtype == torch.int64 and int(s["mask"][0, 0]) == C - 1            # cityscapes.py:42
     assert int(s["mask"].min()) >= 0 and tuple(s["depth"].shape) == (H, W, 1)          # notebook: depth (128,256,1)
     assert torch.equal(s["depth"], torch.from_numpy(raw["depth"]))                     # max <= 1: not rescaled
-    # NYUv2-style sample: 8-bit image range, depth in metres with max_depth 10 (nyuv2.py:118-130, cfg.py:142)
-    raw2 = {"img": rng.integers(0, 256, (H, W, 3)).astype(np.float32), "mask": rng.integers(0, 14, (H, W)),
-            "depth": rng.random((H, W), dtype=np.float32) * 9.0 + 1.0}
-    s2 = data.prepare_sample(raw2, num_classes=14, max_depth=10.0)
-    assert float(s2["img"].max()) <= 1.0 and tuple(s2["depth"].shape) == (H, W, 1)
-    assert torch.allclose(s2["depth"][..., 0], torch.from_numpy(raw2["depth"]) / 10.0)
+    # NYUv2 sample (nyuv2.py:100-141; the module itself needs h5py / torchvision, absent offline, so the expectations are
+    # written out from its rules): 8-bit image -> /255; a class-id mask that ToTensor scaled by 1/255 -> back to ids;
+    # depth = uint16 PNG counts / 1e4 (metres), then / max_depth (cfg.py NYUv2Config.max_depth = 10) because max > 1
+    ids = rng.integers(0, 14, (H, W))
+    counts = rng.integers(5000, 60000, (H, W)).astype(np.uint16)
+    raw2 = {"img": rng.integers(0, 256, (H, W, 3)).astype(np.float32), "mask": (ids / 255.0).astype(np.float32)[None],
+            "depth": counts.astype(np.int32)[None]}
+    s2 = data.prepare_sample(raw2, num_classes=14, max_depth=10.0, dataset="nyuv2")
+    assert float(s2["img"].max()) <= 1.0 and torch.allclose(s2["img"], torch.from_numpy(raw2["img"]) / 255)
+    assert s2["mask"].dtype == torch.int64 and torch.equal(s2["mask"], torch.from_numpy(ids))
+    assert tuple(s2["depth"].shape) == (H, W, 1)
+    assert torch.allclose(s2["depth"][..., 0], torch.from_numpy(counts.astype(np.float32)) / 1e4 / 10.0)
+    assert 0.05 <= float(s2["depth"].min()) and float(s2["depth"].max()) <= 0.6   # SILog-range targets, not 1e3..1e4
+    # an integer-id mask is left alone, and without the dataset name the uint16 depth would NOT be rescaled by 1e4:
+    s3 = data.prepare_sample({"img": raw2["img"], "mask": ids, "depth": counts.astype(np.float32)}, 14, 10.0, dataset="nyuv2")
+    assert torch.equal(s3["mask"], torch.from_numpy(ids)) and torch.allclose(s3["depth"], s2["depth"])
+    s4 = data.prepare_sample({"img": raw["img"], "mask": ids, "depth": counts.astype(np.float32)}, 14, 10.0)
+    assert float(s4["depth"].min()) >= 500.0  # cityscapes rule on the same numbers: only / max_depth
+    with pytest.raises(ValueError):
+        data.prepare_sample(raw2, 14, 10.0, dataset="kitti")
     b = data.collate([s, s], pin=False)
     assert tuple(b["img"].shape) == (2, H, W, 3) and tuple(b["mask"].shape) == (2, H, W) and tuple(b["depth"].shape) == (2, H, W, 1)
     with pytest.raises(ValueError):

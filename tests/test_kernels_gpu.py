@@ -85,13 +85,13 @@ def test_conv2d_fwd_bwd(dev, case):
 
 
 @pytest.mark.parametrize("tile", list(range(16)))
-def test_conv2d_every_tile_config(dev, tile, monkeypatch):
+def test_conv2d_every_tile_config(dev, tile, vmtl_env):
     """Each implicit-GEMM tile configuration (ids in conv_igemm.hip, incl. the tail-column ones) forced
     through the tuning override on one ragged shape: values, pad zeros, BatchNorm partials, data gradient."""
     ops = _ops()
     from vision_mtl_amd._lib import lib
 
-    monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
+    vmtl_env("VMTL_FORCE_TILE", str(tile))
     B, Cin, H, W, Cout = 3, 37, 21, 19, 70
     g = torch.Generator().manual_seed(900 + tile)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -119,12 +119,12 @@ def test_conv2d_every_tile_config(dev, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("tile", [3, 4, 5, 6, 7, 10, 11])
-def test_conv2d_bf16x3_operand_split(dev, tile, monkeypatch):
+def test_conv2d_bf16x3_operand_split(dev, tile, vmtl_env):
     """Opt-in VMTL_BF16X3=1: fp32 operands split exactly into three bf16 planes, six bf16 MFMAs per product.
     Held to a TIGHTER bar than the fp32-MFMA path (2e-6 of the output magnitude): it is an fp32-accurate
     formulation, not a reduced-precision one.  Forward values, BatchNorm partials, data gradient."""
     ops = _ops()
-    monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
+    vmtl_env("VMTL_FORCE_TILE", str(tile))
     B, Cin, H, W, Cout = 2, 120, 17, 23, 150  # K = 9*120 = 1080: above the K >= 768 gate of the variant
     g = torch.Generator().manual_seed(1900 + tile)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -134,7 +134,7 @@ def test_conv2d_bf16x3_operand_split(dev, tile, monkeypatch):
     dxr = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("VMTL_BF16X3", mode)
+        vmtl_env("VMTL_BF16X3", mode)
         xd = to_dev_nhwc(x, dev).requires_grad_(True)
         y, stats = ops.conv2d(xd, w.to(dev), None, stride=1, pad=1, want_stats=True)
         y.backward(to_dev_nhwc(gy, dev))
@@ -148,10 +148,10 @@ def test_conv2d_bf16x3_operand_split(dev, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("rows", [16, 32, 48, 64, 80, 144, 20, 36, 68])
-def test_conv2d_wgrad_every_row_config(dev, rows, monkeypatch):
+def test_conv2d_wgrad_every_row_config(dev, rows, vmtl_env):
     """Each weight-gradient tile height (incl. the VALU tail-row ones) forced through the tuning override."""
     ops = _ops()
-    monkeypatch.setenv("VMTL_FORCE_WG_ROWS", str(rows))
+    vmtl_env("VMTL_FORCE_WG_ROWS", str(rows))
     B, Cin, H, W, Cout = 2, 21, 19, 23, 70
     g = torch.Generator().manual_seed(700 + rows)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -223,8 +223,8 @@ def test_up2_conv(dev, case):
 
 
 @pytest.mark.parametrize("tile", [0, 3, 5, 9, 12, 13, 14, 15])
-def test_up2_conv_forced_tile(dev, tile, monkeypatch):
-    monkeypatch.setenv("VMTL_FORCE_TILE", str(tile))
+def test_up2_conv_forced_tile(dev, tile, vmtl_env):
+    vmtl_env("VMTL_FORCE_TILE", str(tile))
     _check_up2(dev, (2, 24, 6, 10, 12, 35))
 
 

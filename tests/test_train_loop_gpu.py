@@ -112,3 +112,63 @@ def test_training_loop_matches_oracle(dev, mode):
                 arena.adam_step(lr=LR)
     for k, (a, b) in enumerate(zip(got, ref)):
         assert abs(a - b) <= 2e-4 * abs(b), f"{mode}: step {k} loss {a} vs oracle {b}"
+
+
+def test_graphed_step_matches_eager_with_changing_batches(dev):
+    """vision_mtl_amd.graphed.GraphedStep (the product-side captured step): 4 replays on 4 DIFFERENT batches, Adam
+    between them, against the same loop run eagerly from the same start - losses, parameters after the run, the
+    per-step metrics appended to step_outputs; optimizer.zero_grad() with torch's default set_to_none=True and a
+    loss.backward() on the returned handle are both accepted (the reference loop, training_lit.py:81-98, keeps both)."""
+    from vision_mtl_amd import dp
+    from vision_mtl_amd.data import synthetic_batch
+    from vision_mtl_amd.graphed import GraphedStep
+    from vision_mtl_amd.lit_module import MTLModule
+
+    fx = torch.load(os.path.join(G, "mtan_tiny.pt"), weights_only=False)
+    C = fx["cfg"]["C"]
+    B, _, H, W = fx["batch"]["img"].shape
+    batches = [synthetic_batch(B, H, W, C, seed=100 + i, masked=0.1) for i in range(STEPS)]
+    example = synthetic_batch(B, H, W, C, seed=99)
+
+    def run(graphed):
+        model = _model(fx, dev)
+        module = MTLModule(model, num_classes=C, device=str(dev))
+        arena = dp.FlatArena(model)
+        opt = torch.optim.Adam(module.parameters(), lr=LR)  # torch's own optimizer over the arena's parameter views
+        if graphed:
+            gstep = GraphedStep(module, example, arena=arena)
+            model.load_state_dict(fx["state_dict"])  # undo the BatchNorm-buffer drift of the warm-up / rehearsal steps
+        else:  # the same warm-up history, eagerly (BatchNorm buffers are restored right after anyway)
+            model.load_state_dict(fx["state_dict"])
+        losses = []
+        for b in batches:
+            opt.zero_grad()  # set_to_none=True by default
+            if graphed:
+                loss = gstep(b)
+            else:
+                arena.rebind_grads()
+                loss = module.training_step({k: v.to(dev) for k, v in b.items()}, 0)
+            loss.backward()
+            opt.step()
+            dp.ops.packs.invalidate()
+            losses.append(float(loss.detach()))
+        so = {k: [float(v) for v in vals] for k, vals in module.step_outputs["train"].items()}
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, so
+
+    le, sde, soe = run(False)
+    lg, sdg, sog = run(True)
+    assert le[-1] != le[0]
+    for k, (a, b) in enumerate(zip(lg, le)):
+        assert abs(a - b) <= 1e-5 * abs(b), f"step {k}: replayed loss {a} vs eager {b}"
+    for k in sde:
+        if sde[k].is_floating_point():
+            assert_close_(sdg[k], sde[k], k)
+    assert len(sog["loss"]) == STEPS and all(len(v) == STEPS for v in sog.values())
+    for k in soe:
+        for a, b in zip(sog[k], soe[k]):
+            assert (a != a and b != b) or abs(a - b) <= 1e-5 * max(abs(b), 1e-6), f"step_outputs[{k}]: {a} vs {b}"
+
+
+def assert_close_(a, b, what):
+    err, ref = float((a.double() - b.double()).abs().max()), float(b.double().abs().max())
+    assert err <= 1e-5 * ref + 1e-8, f"{what}: {err:.3e} vs magnitude {ref:.3e}"

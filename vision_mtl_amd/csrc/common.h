@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define VMTL_OK 0
 #define VMTL_ERR_ARG (-1)
@@ -38,6 +39,25 @@ static inline int vmtl_check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) vmtl_last_hip_error = (int)e;
   return e == hipSuccess ? VMTL_OK : VMTL_ERR_LAUNCH;
+}
+
+// Tuning overrides (VMTL_FORCE_TILE, VMTL_BF16X3, ...) are read from the environment ONCE, on first use - never per
+// launch (getenv walks the whole environment block: host cost on the eager path).  vmtl_reload_env() bumps the epoch so
+// that the next use re-reads them (the parity tests toggle them between cases).
+extern int vmtl_env_epoch;  // version.hip
+struct EnvInt {
+  const char* name;
+  int dflt;
+  int value = 0;
+  int epoch = 0;
+};
+static inline int env_int(EnvInt& e) {
+  if (e.epoch != vmtl_env_epoch) {
+    const char* s = getenv(e.name);
+    e.value = s ? atoi(s) : e.dflt;
+    e.epoch = vmtl_env_epoch;
+  }
+  return e.value;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -26,8 +26,6 @@
 // 16 bytes) and slot s of row r lives at slot s ^ (r & 7): with that swizzle every 16-lane group of the
 // fragment ds_read_b128 (and every 8-lane group of the staging ds_write_b128) touches 16 (8) distinct
 // slots - conflict-free, where the padded [row][BK+4] layout measured 36 % conflict cycles.
-#include <stdlib.h>
-
 #include "common.h"
 
 #define BK 32
@@ -717,8 +715,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 // ---------------------------------------------------------------------------
 // weight gradient:  slab[z][n][kk] = sum_{m in pixel slice z} dY[m][n] * Xcol[m][kk]
 // A operand = dY rows (i = n), B operand = im2col(X) (j = kk), k = pixel.
-// LDS tiles are [pixel][channel] exactly as they sit in HBM, so fragment reads are
-// conflict-free ds_read_b32 (16 consecutive floats per lane quarter).  Each pixel slice
+// LDS tiles are [pixel][channel] exactly as they sit in HBM; a fragment read is a ds_read_b32 of 16 consecutive
+// floats per lane quarter, quarter q reading pixel row 4s+q.  ds_read_b32 is served in two groups of 32 lanes over 32
+// banks, so the quarters of a group (consecutive pixel rows) must land on disjoint bank ranges: the row stride is padded to
+// == 16 (mod 64) floats (wg_ld below).  Round 2 used stride = width + 4 (== 4 or 20 mod 32): 12 (4) of the 16 banks
+// of the two quarters overlapped - 0.38-0.41 of the LDS cycles were bank conflicts (profiles/r02_*_pmc.json).
+// Each pixel slice
 // writes its own slab with plain stores; vmtl_unpack_weights sums the slabs in a fixed
 // order (deterministic, no float atomics) while converting to the torch layout.
 // ---------------------------------------------------------------------------
@@ -742,6 +744,12 @@ struct WgradP {
 #define BP 32
 #define WG_BNK 128  // kk columns per workgroup (4 waves x 2 tiles x 16)
 
+// smallest row stride >= w (floats, multiple of 4) that is == 16 (mod 64): the four pixel rows of one fragment read
+// start 16 banks apart whether the hardware serves the 64 lanes over 64 banks at once or as two 32-lane groups over 32
+__host__ __device__ constexpr int wg_ld(int w) { return ((w + 47) / 64) * 64 + 16; }
+static_assert(wg_ld(16) == 16 && wg_ld(20) == 80 && wg_ld(144) == 144 && wg_ld(128) == 144 && wg_ld(68) == 80 &&
+              wg_ld(80) == 80 && wg_ld(84) == 144, "wg_ld");
+
 // co rows per workgroup = TM * 16 (+ NTR "tail" rows: the 33rd / 17-20th / 65-68th output channel is not
 // given an MFMA tile of its own - each lane multiplies its X fragment with the tail dY values on the VALU,
 // the same trick as the tail columns of conv_igemm_kernel); waves are laid out 1 x 4 along kk
@@ -750,8 +758,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int TN = 2;
   constexpr int BMM = TM * 16;    // rows covered by MFMA tiles
   constexpr int BMC = BMM + NTR;  // + tail rows
-  constexpr int LDY = BMC + 4;
-  constexpr int LDX = WG_BNK + 4;
+  constexpr int LDY = wg_ld(BMC);
+  constexpr int LDX = wg_ld(WG_BNK);
   constexpr int YQ = BMC / 4;                 // float4 per dY row
   constexpr int YIT = (BP * YQ + 255) / 256;  // loader iterations for the dY tile
   constexpr int XQ = WG_BNK / 4;              // 32 float4 per X row
@@ -978,11 +986,16 @@ static int pick_from(const int* ids, int n, int ncols) {
 
 static bool conv_bf16x3();
 
+// VMTL_FORCE_TILE=id: every launch uses that tile configuration (cached, see env_int)
+static int forced_tile() {
+  static EnvInt e{"VMTL_FORCE_TILE", -1};
+  const int id = env_int(e);
+  return (id >= 0 && id < VMTL_NTILES) ? id : -1;
+}
+
 static int conv_pick_tile(int M, int ncols) {
-  if (const char* f = getenv("VMTL_FORCE_TILE")) {  // tuning aid (tools/bench_conv.py), never set in production
-    const int id = atoi(f);
-    if (id >= 0 && id < VMTL_NTILES) return id;
-  }
+  const int forced = forced_tile();  // tuning aid (tools/bench_conv.py), never set in production
+  if (forced >= 0) return forced;
   const int big = pick_from(kBigIds, VMTL_NBIG, ncols);
   // too few workgroups for 256 CUs: halve the row block
   if ((long long)cdiv(M, 128) * cdiv(ncols, kTiles[big].bn) < 384) return pick_from(kSmallIds, 4, ncols);
@@ -1006,19 +1019,15 @@ static int launch_conv_ns(ConvP& p, hipStream_t st);
 
 // opt-in bf16x3 operand split for the wide tiles (VMTL_BF16X3=1); see the kernel comment
 static bool conv_bf16x3() {
-  const char* e = getenv("VMTL_BF16X3");  // read per call: the parity tests toggle it
-  return e && atoi(e) == 1;
+  static EnvInt e{"VMTL_BF16X3", 0};  // cached; the parity tests toggle it through vmtl_reload_env()
+  return env_int(e) == 1;
 }
 
 // LDS-DMA staging depth: 0 = register staging.  VMTL_GLDS overrides (tuning aid).
 static int conv_glds_stages() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VMTL_GLDS");
-    v = e ? atoi(e) : 0;
-    if (v != 0 && v != 2 && v != 3) v = 0;
-  }
-  return v;
+  static EnvInt e{"VMTL_GLDS", 0};
+  const int v = env_int(e);
+  return (v == 2 || v == 3) ? v : 0;
 }
 
 template <int TM, int TN, int WMV, int WNV, bool UP2 = false, int NT = 0>
@@ -1199,10 +1208,8 @@ extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, flo
 // to conv3x3(cat[nearest2(xl), skip]) up to fp32 summation order, with 4 instead of 9 taps on the
 // upsampled channels and no materialised upsample / concat tensor.
 static int up2_pick_tile(int Mq, int ncols) {
-  if (const char* f = getenv("VMTL_FORCE_TILE")) {
-    const int id = atoi(f);
-    if (id >= 0 && id < VMTL_NTILES) return id;
-  }
+  const int forced = forced_tile();
+  if (forced >= 0) return forced;
   int big = pick_from(kBigIds, VMTL_NBIG, ncols);
   // 65-68 columns: the phase convs run faster on five MFMA column fragments (80 columns, 12 idle) than on four plus
   // four VALU tail columns - measured 364 vs 392 us on the 135+16 -> 67 layer (tools/bench_up2.py); the plain 3x3
@@ -1262,8 +1269,8 @@ static int wgrad_rows(int Nw) {
   // 20 / 36 / 68 = 16 / 32 / 64 MFMA rows + 4 tail rows on the VALU
   static const int cands[] = {16, 32, 48, 64, 80, 144, 20, 36, 68};
   static const float eff[] = {0.35f, 0.55f, 0.72f, 0.82f, 0.88f, 1.0f, 0.43f, 0.61f, 0.86f};
-  if (const char* f = getenv("VMTL_FORCE_WG_ROWS")) {  // tuning aid
-    const int v = atoi(f);
+  static EnvInt force{"VMTL_FORCE_WG_ROWS", 0};  // tuning aid
+  if (const int v = env_int(force)) {
     for (int i = 0; i < 9; ++i)
       if (cands[i] == v) return v;
   }
@@ -1288,21 +1295,14 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   // whose tile grid is a few dozen workgroups): there 4 K-steps per slice, parallelism over the chip beats the longer
   // slab sum (the 1x1 weight gradients at M = 1024 / 4096 ran 45-60 us on 28-72 workgroups; basic bs32 14.4 -> 14.0
   // ms/step).  Extending the rule to 65536 / all sizes measured +0.05..0.1 ms (VMTL_WG_SMALL_M).
-  static int min_steps = -1, small_m = -1;
-  if (min_steps < 0) {
-    const char* e = getenv("VMTL_WG_MIN_STEPS");  // tuning aids
-    min_steps = e ? atoi(e) : 4;
-    if (min_steps < 1) min_steps = 1;
-    const char* e2 = getenv("VMTL_WG_SMALL_M");
-    small_m = e2 ? atoi(e2) : 16384;
-  }
+  static EnvInt e_steps{"VMTL_WG_MIN_STEPS", 4}, e_small{"VMTL_WG_SMALL_M", 16384}, e_splits{"VMTL_FORCE_WG_SPLITS", 0};  // tuning aids
+  const int min_steps = env_int(e_steps) < 1 ? 1 : env_int(e_steps), small_m = env_int(e_small);
   const long long max_by_rows = cdiv(M, (M <= small_m ? min_steps : 16) * BP);
   const long long max_by_mem = (32ll << 20) / ((long long)Nw * Ktot);  // slabs <= 128 MB
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits > max_by_mem) splits = max_by_mem;
   if (splits < 1) splits = 1;
-  if (const char* f = getenv("VMTL_FORCE_WG_SPLITS")) {  // tuning aid
-    const long long v = atoll(f);
+  if (const long long v = env_int(e_splits)) {
     if (v >= 1 && v <= max_by_rows) splits = v;
   }
   const int chunk = cdiv(cdiv(M, (int)splits), BP) * BP;
@@ -1312,7 +1312,7 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
 template <int TM, int NTR = 0>
 static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
   constexpr int BMC = TM * 16 + NTR;
-  const size_t lds = (size_t)2 * BP * ((BMC + 4) + (WG_BNK + 4)) * sizeof(float);
+  const size_t lds = (size_t)2 * BP * (wg_ld(BMC) + wg_ld(WG_BNK)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, NTR>),

@@ -284,10 +284,9 @@ static void pw_pick(int M, int ldy, int Ks, int* tn, int* kw) {
   const int bn = 16 * *tn;
   const long long wgs = (long long)cdiv(M, 128) * cdiv(ldy, bn);
   *kw = (wgs < 512 && Ks >= 64) ? 4 : 1;
-  if (const char* f = getenv("VMTL_PW_KW")) {  // tuning aid
-    const int v = atoi(f);
-    if (v == 1 || v == 4) *kw = v;
-  }
+  static EnvInt force{"VMTL_PW_KW", 0};  // tuning aid
+  const int v = env_int(force);
+  if (v == 1 || v == 4) *kw = v;
 }
 
 extern "C" int vmtl_conv1x1_stats_block(int M, int ldy, int Ks) {

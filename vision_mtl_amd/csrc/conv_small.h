@@ -45,6 +45,13 @@
 #define CSM_OT4 1152                       // float4 of the output tile image: 128 pixels x (<= 36 floats)
 #define CSM_RED4 512                       // float4 of the statistics scratch: [2][4 waves][64 lanes]
 
+// ablation switches of the kernel below (skip stores / staging / MFMAs: WRONG results) exist only in a -DVMTL_TUNING build
+#ifdef VMTL_TUNING
+#define CSM_DBG(p) ((p).dbg)
+#else
+#define CSM_DBG(p) 0
+#endif
+
 struct SmallP {
   const float* x;    // [B][H][W][CS]
   const float* x2;   // optional second prologue operand, same shape
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // CU-exact pairing: the hardware id of the CU this workgroup landed on (XCC, SE, SH, CU) indexes a ticket counter;
     // the second workgroup to arrive on a CU (odd ticket) starts half a tile period late.  Tickets are never reset:
     // with two workgroups per CU and launch the parity alternates by itself.
-    const int mode = (p.dbg >> 3) & 3;  // tuning aid: 0 ticket per CU, 1 nobody, 2 upper half of the grid, 3 odd ids
+    const int mode = (CSM_DBG(p) >> 3) & 3;  // tuning aid: 0 ticket per CU, 1 nobody, 2 upper half of the grid, 3 odd ids
     int late = 0;
     if (tid == 0) {
       if (mode == 0) {
@@ -281,15 +288,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (; t < p.ntiles; t += gridDim.x) {
     const int b = nb, h0 = nh0, w0 = nw0;
     lds_barrier();  // every wave is done with the previous tile's LDS image (first pass: weights / coef are in LDS)
-    if (!(p.dbg & 2)) stage_store(b, h0, w0);
+    if (!(CSM_DBG(p) & 2)) stage_store(b, h0, w0);
     lds_barrier();
-    if (t + (int)gridDim.x < p.ntiles && !(p.dbg & 2)) {  // global loads stay in flight under the MFMAs
+    if (t + (int)gridDim.x < p.ntiles && !(CSM_DBG(p) & 2)) {  // global loads stay in flight under the MFMAs
       tile_origin(t + gridDim.x, nb, nh0, nw0);
       prefetch(nb, nh0, nw0);
     }
     // this wave's output row; the mode-2 operand of this tile is fetched under the MFMAs too
     const int h = h0 + wv;
-    const bool rowok = h < p.H && !(p.dbg & 1);
+    const bool rowok = h < p.H && !(CSM_DBG(p) & 1);
     const int pixrow = (b * p.H + h) * p.W + w0;  // + pixel of the row
     f32x4 rz[EIT];
     if (p.ep_mode == 2) {
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // groups' reads to the top (which spilled: 21 groups x 12 fragments).
     Frag fr[2];
     load_frag(0, fr[0]);
-    if (!(p.dbg & 4))
+    if (!(CSM_DBG(p) & 4))
 #pragma unroll
     for (int g = 0; g < NGF + NGR; ++g) {
       if (g + 1 < NGF + NGR) load_frag(g + 1, fr[(g + 1) & 1]);
@@ -591,7 +598,7 @@ static int launch_small_x(SmallP& p, hipStream_t st) {
     return VMTL_ERR_LAUNCH;
   static_assert(C::LDS_BYTES * 2 <= 160 * 1024, "two workgroups per CU (small_grid() assumes it)");
   int grid = p.grid;
-  if (p.dbg & 64) grid = small_cus() < p.ntiles ? small_cus() : p.ntiles;  // tuning aid: one workgroup per CU
+  if (CSM_DBG(p) & 64) grid = small_cus() < p.ntiles ? small_cus() : p.ntiles;  // tuning aid: one workgroup per CU
   hipLaunchKernelGGL((conv3x3_small_kernel<CS, TN, NT, X2>), dim3(grid), dim3(256), C::LDS_BYTES, st, p);
   return vmtl_check_launch();
 }

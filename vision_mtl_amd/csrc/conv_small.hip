@@ -30,11 +30,8 @@ int small_grid(int ntiles, int* acc_rows) {
   for (int g = slots < ntiles ? slots : ntiles; g >= 1; --g)
     if (ntiles % g == 0) { best = g; break; }
   if (acc_rows) *acc_rows = 0;
-  static int allow = -1;  // VMTL_SMALL_ACC=0: tuning aid, one statistics row per tile
-  if (allow < 0) {
-    const char* e = getenv("VMTL_SMALL_ACC");
-    allow = e ? atoi(e) : 1;
-  }
+  static EnvInt e_acc{"VMTL_SMALL_ACC", 1};  // VMTL_SMALL_ACC=0: tuning aid, one statistics row per tile
+  const int allow = env_int(e_acc);
   if (allow && best * 2 >= (slots < ntiles ? slots : ntiles)) {
     if (acc_rows) *acc_rows = 1;
     return best;
@@ -86,8 +83,12 @@ extern "C" int vmtl_conv3x3_small(const float* x, const float* x2, const float* 
   p.B = B; p.H = H; p.W = W; p.ldy = ldy; p.Nw = Nw; p.Cout = Cout;
   p.tiles_x = cdiv(W, CSM_TW); p.tiles_y = cdiv(H, CSM_TH); p.ntiles = B * p.tiles_x * p.tiles_y;
   p.grid = small_grid(p.ntiles, &p.acc_rows);
-  const char* dbg = getenv("VMTL_SMALL_DBG");
-  p.dbg = dbg ? atoi(dbg) : 0;
+#ifdef VMTL_TUNING  // ablation switches (WRONG results): only in a -DVMTL_TUNING build, never in the shipped library
+  static EnvInt e_dbg{"VMTL_SMALL_DBG", 0};
+  p.dbg = env_int(e_dbg);
+#else
+  p.dbg = 0;
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (ldy > (Nw > 20 ? 36 : 20)) return VMTL_ERR_ARG;  // the output tile holds 16 / 32 MFMA columns + 4
   switch (Cs) {

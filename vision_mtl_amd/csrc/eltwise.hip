@@ -453,6 +453,30 @@ extern "C" int vmtl_axpby(const float* a, const float* b, float* y, float wa, fl
   return vmtl_check_launch();
 }
 
+// y = a + b (+ c) (+ d) on float4 lanes: the gradient sum of an activation with 2..4 consumers (ops.fork) - autograd's own
+// accumulation would be n-1 ATen launches over 3 (n-1) tensor passes, this is one launch over n + 1
+__global__ __launch_bounds__(256) void add_n_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                                    const f32x4* __restrict__ c, const f32x4* __restrict__ d,
+                                                    f32x4* __restrict__ y, long long n4) {
+  GRID_STRIDE(i, n4) {
+    f32x4 r = a[i] + b[i];
+    if (c != nullptr) r += c[i];
+    if (d != nullptr) r += d[i];
+    y[i] = r;
+  }
+}
+
+// c / d may be null; total % 4 == 0 and 16-byte aligned operands (activations in this library always are)
+extern "C" int vmtl_add_n(const float* a, const float* b, const float* c, const float* d, float* y, long long total,
+                          void* stream) {
+  VMTL_ENTER();
+  if (!a || !b || !y || total <= 0 || (total & 3) || (d && !c)) return VMTL_ERR_ARG;
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)y) & 15) != 0) return VMTL_ERR_ARG;
+  hipLaunchKernelGGL(add_n_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a,
+                     (const f32x4*)b, (const f32x4*)c, (const f32x4*)d, (f32x4*)y, total / 4);
+  return vmtl_check_launch();
+}
+
 extern "C" int vmtl_eltwise(const float* a, const float* b, float* y, int mode, long long total, void* stream) {
   VMTL_ENTER();
   if (!a || !y || total <= 0 || mode < 0 || mode > 3 || (mode != 1 && !b)) return VMTL_ERR_ARG;

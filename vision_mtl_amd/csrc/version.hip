@@ -7,6 +7,10 @@ extern "C" const char* vmtl_version(void) { return "vmtl 0.1 (gfx950)"; }
 
 thread_local int vmtl_last_hip_error = 0;
 
+int vmtl_env_epoch = 1;
+// re-read the VMTL_* tuning overrides on their next use (they are cached after the first read)
+extern "C" int vmtl_reload_env(void) { return ++vmtl_env_epoch; }
+
 // HIP's description of the last launch failure seen on this thread (status -2), for error messages
 extern "C" const char* vmtl_last_error_string(void) { return hipGetErrorString((hipError_t)vmtl_last_hip_error); }
 

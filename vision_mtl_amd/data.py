@@ -33,25 +33,44 @@ def synthetic_batch(B: int, H: int, W: int, C: int, seed: int = 11, masked: floa
     return {"img": img, "mask": mask, "depth": depth}
 
 
-def prepare_sample(raw: dict, num_classes: int, max_depth: float = 1.0) -> dict:
-    """Value rules of reference data_modules/cityscapes.py:39-67 (and nyuv2.py:100-141) on one raw sample
-    {"img": (H,W,3), "mask": (H,W), "depth": (H,W) or (H,W,1)} of numpy arrays / tensors, WITHOUT the CHW transpose:
-    mask == -1 -> num_classes-1, img float32 (8-bit range rescaled to [0,1]), mask int64, depth float32 divided by
-    max_depth when it exceeds 1 (common_ds.py:47-50) and shaped (H, W, 1) (SILog needs the trailing 1)."""
+def prepare_sample(raw: dict, num_classes: int, max_depth: float = 1.0, dataset: str = "cityscapes") -> dict:
+    """Value rules of the reference's two datasets on one raw sample {"img": (H,W,3), "mask": (H,W), "depth": (H,W) or
+    (H,W,1)} of numpy arrays / tensors, WITHOUT the CHW transpose.
+
+    dataset="cityscapes" (reference data_modules/cityscapes.py:39-67): mask == -1 -> num_classes-1, img float32, mask
+    int64, depth float32 divided by max_depth when its maximum exceeds 1 (common_ds.py:47-50).
+    dataset="nyuv2" (reference data_modules/nyuv2.py:100-141): img divided by 255 when its maximum exceeds 1 (8-bit
+    PNG), a mask that a ToTensor transform scaled into [0,1] is multiplied back by 255 (`mask.max() <= 1.0`), mask
+    squeezed to (H,W) int64 with NO -1 remap, depth = uint16 PNG value / 1e4 and THEN the max_depth rule
+    (NYUv2Config.max_depth = 10: cfg.py:117-155).  Leaving the /1e4 step out trains SILog on targets in the 1e3-1e4
+    range with no error, so the dataset has to be named - there is no way to tell a raw uint16 map from metres.
+
+    Both: depth comes back as (H, W, 1) (SILog needs the trailing 1)."""
+    if dataset not in ("cityscapes", "nyuv2"):
+        raise ValueError(f"prepare_sample: dataset must be 'cityscapes' or 'nyuv2', got {dataset!r}")
     as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
-    img, mask, depth = as_t(raw["img"]).float(), as_t(raw["mask"]).long().clone(), as_t(raw["depth"]).float().clone()
+    img, mask, depth = as_t(raw["img"]).float(), as_t(raw["mask"]).clone(), as_t(raw["depth"]).float().clone()
     if img.dim() != 3 or img.shape[-1] != 3:
         raise ValueError(f"prepare_sample: img must be (H, W, 3), got {tuple(img.shape)}")
-    if img.max() > 1.0:  # nyuv2.py:118-119
-        img = img / 255
-    mask[mask == -1] = num_classes - 1  # cityscapes.py:42
+    if dataset == "nyuv2":
+        if img.max() > 1.0:  # nyuv2.py:118-119
+            img = img / 255
+        if mask.is_floating_point() and mask.max() <= 1.0:  # nyuv2.py:121-123: ToTensor scaled the class ids by 1/255
+            mask = (mask * 255).round()
+        mask = mask.squeeze().long()  # nyuv2.py:124
+        depth = depth / 1e4  # nyuv2.py:126-127: the depth PNG is uint16, 1e-4 m per count
+    else:
+        mask = mask.long()
+        mask[mask == -1] = num_classes - 1  # cityscapes.py:42
     if depth.max() > 1.0:  # common_ds.py:47-50
         depth /= max_depth
+    if depth.dim() == 3 and depth.shape[0] == 1 and depth.shape[-1] != 1:  # nyuv2.py:130-131: (1,H,W) -> (H,W,1)
+        depth = depth.permute(1, 2, 0)
     if depth.dim() == 2:
         depth = depth.unsqueeze(-1)
     if tuple(mask.shape) != tuple(img.shape[:2]) or tuple(depth.shape) != (*img.shape[:2], 1):
         raise ValueError("prepare_sample: img / mask / depth sizes differ")
-    return {"img": img.contiguous(), "mask": mask, "depth": depth}
+    return {"img": img.contiguous(), "mask": mask, "depth": depth.contiguous()}
 
 
 def collate(samples: t.Sequence[dict], pin: bool = True) -> dict:

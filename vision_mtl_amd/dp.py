@@ -40,7 +40,11 @@ class FlatArena:
     is one memset of the flat buffer (needed only for the autograd-accumulated kind).
 
     Use from a driver loop that owns the optimizer step (bench.py, ArenaAdam below).  Do not combine
-    with optimizer.zero_grad(set_to_none=True): .grad must stay bound to the arena."""
+    with optimizer.zero_grad(set_to_none=True): .grad must stay bound to the arena (rebind_grads() re-attaches it).
+
+    COLLECTIVE CONSTRUCTOR: with an initialised process group, FlatArena(model) broadcasts rank 0's parameters and
+    buffers (broadcast=True, the default) - EVERY rank must construct its arena, in the same order, or the ranks that do
+    wait forever.  Pass broadcast=False for a rank-local arena (and call broadcast_parameters() yourself later)."""
 
     def __init__(self, model: torch.nn.Module, broadcast: bool = True):
         params = [p for p in model.parameters() if p.requires_grad]
@@ -51,7 +55,9 @@ class FlatArena:
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params, self.offsets, off = params, [], 0
-        self._kernel_written = set()  # ids of parameters whose slot a HIP backward kernel writes (ops._slot)
+        self._kernel_written = set()  # ids of parameters whose slot a HIP backward kernel writes (ops._slot); per step
+        self._nonzero_bias = set()    # ids of bias parameters whose slot holds column sums (see ops._bias_grad)
+        self._scale_consumer = None   # weak reference to the ArenaAdam that folds pending_scale into its update
         self._hooks = []
         for p in params:
             n = p.numel()
@@ -125,6 +131,8 @@ class FlatArena:
             for attr in ("_vmtl_gslot", "_vmtl_arena"):
                 if hasattr(p, attr):
                     delattr(p, attr)
+        self._scale_consumer = None
+        self._kernel_written.clear()
         if getattr(self.model, "dp_arena", None) is self:
             self.model.dp_arena = None
 
@@ -132,6 +140,14 @@ class FlatArena:
         """One memset of the whole gradient buffer (slots written by kernels do not need it: they are overwritten)."""
         self.flat_grad.zero_()
         self.pending_scale = 1.0
+        self._nonzero_bias.clear()
+
+    def rebind_grads(self) -> None:
+        """Re-attach every parameter's .grad to its arena slot (after an optimizer.zero_grad(set_to_none=True), torch
+        2.x's default, which only drops the Python binding: the kernels keep writing into the slots)."""
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
     def all_reduce_mean(self):
         """Average the flat gradient over all ranks: ONE collective.  On RCCL (backend nccl) the averaging is the
@@ -158,9 +174,14 @@ class FlatArena:
 
     def _end_of_backward(self):
         scale = self.all_reduce_mean()
+        self._kernel_written.clear()  # the guard covers one backward pass; the next forward re-registers its slots
         if scale != 1.0:
-            if getattr(self, "_scale_consumer", None) is not None:
-                self.pending_scale = scale  # ArenaAdam.step() passes it as grad_scale: no extra pass
+            consumer = self._scale_consumer() if self._scale_consumer is not None else None
+            if consumer is not None:
+                # the attached ArenaAdam folds the factor into its fused update (no extra pass over 54 MB).  Until its
+                # step() - or adam_step() - runs, flat_grad holds the SUM over ranks: anything else that reads gradients
+                # in between (clipping, logging) must multiply by arena.pending_scale
+                self.pending_scale = scale
             else:
                 self.flat_grad.mul_(scale)
 
@@ -172,8 +193,12 @@ class FlatArena:
         ops.side.join()
         st = self._adam
         st["step"] += 1
+        # a 1/world factor still owed to the gradient (gloo: all_reduce_mean returned it to _end_of_backward) is consumed
+        # HERE, whoever calls: a direct adam_step() after a discarded ArenaAdam cannot silently drop it
+        grad_scale, self.pending_scale = grad_scale * self.pending_scale, 1.0
         ops.adam_step(self.flat_param, self.flat_grad, st["m"], st["v"], st["step"], lr, betas, eps, weight_decay,
                       grad_scale)
+        self._kernel_written.clear()
         ops.packs.invalidate()  # parameters changed through raw pointers: packed operands are stale
 
 
@@ -190,15 +215,13 @@ class ArenaAdam(torch.optim.Optimizer):
     def __init__(self, arena: "FlatArena", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.arena = arena
         super().__init__([arena.flat_param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        arena._scale_consumer = self
+        arena._scale_consumer = weakref.ref(self)  # weak: a discarded optimizer stops deferring the 1/world factor
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
-        scale, self.arena.pending_scale = self.arena.pending_scale, 1.0
-        self.arena.adam_step(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"],
-                             grad_scale=scale)
+        self.arena.adam_step(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
         return loss
 
     def zero_grad(self, set_to_none: bool = False):
@@ -268,6 +291,10 @@ class _SyncGrads(torch.autograd.Function):
     def backward(ctx, g):
         torch.autograd.Variable._execution_engine.queue_callback(ctx.arena._end_of_backward)
         return g, None
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def init_distributed():

@@ -37,12 +37,13 @@ def to_nchw(a: Act) -> torch.Tensor:
     return ops.to_nchw(a.t, a.C)
 
 
-def fork(a: Act):
-    """Two handles on an activation with two consumers; their gradients are summed by this library's kernel."""
+def fork(a: Act, n: int = 2):
+    """n handles on an activation with n consumers; their gradients are summed by this library's kernel (one launch)."""
+    if n == 1:
+        return (a,)
     if not a.t.requires_grad:
-        return a, a
-    t1, t2 = ops.fork(a.t)
-    return Act(t1, a.C), Act(t2, a.C)
+        return tuple(a for _ in range(n))
+    return tuple(Act(t, a.C) for t in ops.fork(a.t, n))
 
 
 def _momentum(bn: nn.BatchNorm2d) -> float:
@@ -157,7 +158,8 @@ def up2_conv_bn_act(x: Act, skip: Act | None, c: nn.Conv2d, bn: nn.BatchNorm2d, 
     if _pair(c.kernel_size) != 3 or _pair(c.padding) != 1 or _pair(c.stride) != 1 or c.bias is not None:
         raise ValueError("up2_conv_bn_act expects a 3x3 / pad 1 / stride 1 conv without bias")
     y, stats = ops.up2_conv(x.t, x.C, None if skip is None else skip.t, c.weight, want_stats=bn.training)
-    return bn_act(Act(y, c.out_channels), bn, act, None, None, stats)
+    return bn_act(Act(y, c.out_channels), bn, act, None, None, stats,
+                  stats_rpb=getattr(stats, "_vmtl_rpb", 0) if stats is not None else 0)
 
 
 def maxpool2(x: Act) -> Act:

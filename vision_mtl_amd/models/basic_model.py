@@ -37,7 +37,7 @@ class BasicMTLModel(nn.Module):
             # the narrow full-resolution tail (BN+ReLU -> conv2 -> BN+ReLU -> both heads) on the halo-tile kernel
             segm, depth = ops.decoder_tail(x1.t, stats1, rpb1, bn1, c2.weight, bn2, sh.weight, sh.bias, dh.weight, dh.bias)
         else:
-            dec = L.conv_bn_act(L.bn_act(x1, bn1, ops.ACT_RELU, stats=stats1), c2, bn2, ops.ACT_RELU)
+            dec = L.conv_bn_act(L.bn_act(x1, bn1, ops.ACT_RELU, stats=stats1, stats_rpb=rpb1), c2, bn2, ops.ACT_RELU)
             # both 3x3 heads read the same decoder map: one implicit GEMM with N = C + 1 output channels
             segm, depth = ops.dual_head(dec.t, sh.weight, sh.bias, dh.weight, dh.bias, pad=sh.padding[0])
         return dict(depth=depth, segm=segm)

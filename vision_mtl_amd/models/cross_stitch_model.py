@@ -187,8 +187,9 @@ class CSNet(nn.Module):
                     net, f = self.models[task], feats[task]
                     if op == "stitch":
                         feats[task] = self.cross_stitch_layers[arg].run_task(ti, f)
-                    elif op == "save":
-                        skips[task].append(f)
+                    elif op == "save":  # two consumers (the next leaf and a decoder merge): gradients summed by our kernel
+                        feats[task], keep = L.fork(f)
+                        skips[task].append(keep)
                     elif op == "merge":
                         feats[task] = L.pad_cat(f, skips[task][-arg - 1])
                     elif op == "up":

@@ -95,11 +95,17 @@ class MTANDown(nn.Module):
         self.pool = nn.MaxPool2d(2) if apply_pool else nn.Identity()
         self.task_attn_modules = task_attn_modules
 
-    def forward(self, x: L.Act, prev_layer_outs=None):
-        d = self.dconv.run(x)
-        outs = [m(x, d, prev_layer_outs[i] if prev_layer_outs else None)
+    def forward(self, x: L.Act, prev_layer_outs=None, n_out: int = 1):
+        """n_out > 1: the shared feature comes back as that many handles (one per downstream consumer), so that ALL its
+        gradients - both attention gates, the next stage, the decoder skip - are summed by one launch (L.fork)."""
+        T = len(self.task_attn_modules)
+        xs = L.fork(x, T + 1)  # x feeds the shared double conv and every task's attention module
+        ds = L.fork(self.dconv.run(xs[0]), T + n_out)
+        outs = [m(xs[1 + i], ds[i], prev_layer_outs[i] if prev_layer_outs else None)
                 for i, m in enumerate(self.task_attn_modules)]
-        return (L.maxpool2(d) if isinstance(self.pool, nn.MaxPool2d) else d), outs
+        if isinstance(self.pool, nn.MaxPool2d):
+            return L.maxpool2(ds[T]), outs
+        return (ds[T] if n_out == 1 else ds[T:]), outs
 
 
 class MTANUp(nn.Module):
@@ -112,11 +118,13 @@ class MTANUp(nn.Module):
         self.task_attn_modules = task_attn_modules
         self.out_channels, self.in_channels = out_channels, in_channels
 
-    def forward(self, x1: L.Act, x2: L.Act, task_attn_prev_outs):
-        merged = L.pad_cat(L.conv_transpose(x1, self.up), x2)
-        conv_out = self.conv.run(merged)
-        outs = [m(merged, task_attn_prev_outs[i], conv_out) for i, m in enumerate(self.task_attn_modules)]
-        return conv_out, outs
+    def forward(self, x1: L.Act, x2: L.Act, task_attn_prev_outs, last: bool = False):
+        """last: nobody downstream reads the shared feature (the final decoder stage: only the attention gates do)."""
+        T = len(self.task_attn_modules)
+        ms = L.fork(L.pad_cat(L.conv_transpose(x1, self.up), x2), T + 1)
+        cs = L.fork(self.conv.run(ms[0]), T if last else T + 1)
+        outs = [m(ms[1 + i], task_attn_prev_outs[i], cs[i]) for i, m in enumerate(self.task_attn_modules)]
+        return (None if last else cs[T]), outs
 
 
 class MTANMiniUnet(nn.Module):
@@ -157,10 +165,11 @@ class MTANMiniUnet(nn.Module):
         enc = L.from_nchw(x)
         feats, attn = [], None
         for layer in self.enc_layers:
-            d, attn = layer(enc, attn)
-            feats.append(d)
-            enc = L.maxpool2(d)
+            (d_skip, d_next), attn = layer(enc, attn, n_out=2)  # the shared feature goes to the decoder AND the next stage
+            feats.append(d_skip)
+            enc = L.maxpool2(d_next)
         dec = self.bottleneck.run(enc)
+        n = len(self.dec_layers)
         for i, layer in enumerate(self.dec_layers):
-            dec, attn = layer(dec, feats[-(i + 1)], attn)
+            dec, attn = layer(dec, feats[-(i + 1)], attn, last=i == n - 1)
         return {task: L.to_nchw(L.conv(attn[i], head)) for i, (task, head) in enumerate(self.map_tasks_to_heads.items())}

@@ -440,7 +440,7 @@ class Backbone(nn.Module):
         self.encoder = MobileNetV3Encoder(in_channels, depth=num_decoder_layers)
         self.decoder = UnetDecoder(self.encoder.out_channels[: num_decoder_layers + 1], self.decoder_channels)
         if weights_file is not None:
-            sd = torch.load(weights_file, map_location="cpu")
+            sd = torch.load(weights_file, map_location="cpu", weights_only=True)  # a state_dict: tensors only, no pickled code
             sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
             own = self.encoder.model.state_dict()
             # timm's classifier checkpoint also carries conv_head / classifier: features_only drops them

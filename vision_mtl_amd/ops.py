@@ -50,25 +50,11 @@ def _k(name, _flop=None, _xflop=None, **kw):
         # _flop: algorithmic FLOPs of the reference formulation (logical channels); _xflop: FLOPs the launch
         # really executes when an algebraic rewrite makes them differ (up2_conv)
         _RECORD.append((name, dict(kw), float(_flop), float(_flop if _xflop is None else _xflop)))
-    if (_SKIP_SIDE_WORK and side.in_branch) or name in _SKIP_NAMES:
-        return
     lib().callk(name, stream=_stream(), **kw)
-    if _EXTRA_LAUNCHES and name in ("vmtl_bn_stats", "vmtl_bn_stats_coef"):
-        global _EXTRA_BUF
-        if _EXTRA_BUF is None:
-            _EXTRA_BUF = torch.zeros(64, device="cuda")
-        for _ in range(_EXTRA_LAUNCHES):
-            lib().callk("vmtl_fill_zero", p=_EXTRA_BUF, n=4, stream=_stream())
 
 
-# tuning aid: VMTL_DBG_EXTRA=n queues n more (trivial) launches behind every BatchNorm finalize: the marginal cost of a
-# launch on the dependent chain of the forward pass
-_EXTRA_LAUNCHES = int(os.environ.get("VMTL_DBG_EXTRA", "0"))
-_EXTRA_BUF = None
-# tuning aid: VMTL_DBG_SKIP_SIDE=1 drops every launch of the side branch (WRONG gradients; measures the main chain alone)
-_SKIP_SIDE_WORK = os.environ.get("VMTL_DBG_SKIP_SIDE", "0") == "1"
-# VMTL_DBG_SKIP=entry,entry: drop those launches (WRONG results; upper bound of what removing them would gain)
-_SKIP_NAMES = frozenset(n for n in os.environ.get("VMTL_DBG_SKIP", "").split(",") if n)
+# (the launch-dropping ablation switches of round 2 - VMTL_DBG_SKIP_SIDE / VMTL_DBG_SKIP / VMTL_DBG_EXTRA - produce WRONG
+# results by design and are no longer part of the product: tools/dbg_hooks.py installs them around _k on request)
 _STAMPS = None  # bench.py (VMTL_STAMPS=1) sets this to a list to collect a two-stream timeline
 
 
@@ -204,6 +190,18 @@ class _SideBranch:
 
 
 side = _SideBranch()
+
+
+def _remember_mode(ctx):
+    """Output nodes of a model (the first nodes its backward pass runs) keep the stream mode their FORWARD was built in:
+    side.task_mode is process-global and another model's forward may have flipped it before this graph's backward."""
+    ctx.task_mode = side.task_mode
+
+
+def _restore_mode(ctx):
+    side.task_mode = ctx.task_mode
+    if ctx.task_mode:  # task streams were used by this graph: the calling stream joins them when the engine is done
+        side.join_at_end_of_backward()
 
 
 # ----------------------------------------------------------------------------- packing
@@ -427,6 +425,33 @@ def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
     return out
 
 
+def _bias_grad(bias, slot, dy, M, Cout, ldy, zero, fork):
+    """dL/dbias of a conv (column sums of dy), into its arena slot when there is one (returns None then).
+    zero: the conv feeds a TRAIN-mode BatchNorm - the batch mean absorbs the bias, its gradient is exactly 0.  An arena
+    slot is zero from the arena's construction / zero_grad() on and this is its only writer, so nothing is launched
+    unless an earlier (eval-mode BatchNorm) step left column sums there (FlatArena._nonzero_bias keeps track): MTAN's 56
+    attention-conv biases cost 56 memset launches per step before."""
+    arena = getattr(bias, "_vmtl_arena", None) if slot is not None else None
+    if zero:
+        if slot is None:
+            db = _empty((Cout,), dy)
+            _k("vmtl_fill_zero", p=db, n=Cout)
+            return db
+        if arena is None or id(bias) in arena._nonzero_bias:
+            with side.branch(True, M, fork, dy):
+                _k("vmtl_fill_zero", p=slot, n=Cout)
+            if arena is not None:
+                arena._nonzero_bias.discard(id(bias))
+        return None
+    with side.branch(slot is not None, M, fork, dy):
+        db = _colsum(dy, None, M, Cout, ldy, out=slot)
+    if slot is not None:
+        if arena is not None:
+            arena._nonzero_bias.add(id(bias))
+        return None
+    return db
+
+
 FUSE_DW = os.environ.get("VMTL_FUSE_DW", "1") != "0"  # encoder: bn1 + act + depthwise conv as one node (vmtl_dwconv_bn_fwd)
 _PW = os.environ.get("VMTL_PW", "1") != "0"  # pointwise GEMM kernel for 1x1 convs (csrc/conv_pw.hip)
 _PW_MAX_ROWS = int(os.environ.get("VMTL_PW_MAX_ROWS", str(1 << 21)))  # measured on MTAN (M = 2^20): 57.1 -> 55.5 ms/step
@@ -490,6 +515,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.cfg = (stride, pad, bias is not None)
         ctx.zero_bias_grad = bool(zero_bias_grad)
         ctx.slots = (_slot(weight), _slot(bias))
+        ctx.bias = bias
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" tensor for the stats output
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -525,15 +551,7 @@ class _Conv2d(torch.autograd.Function):
             if ctx.slots[0] is not None:
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
-            with side.branch(ctx.slots[1] is not None, B * Ho * Wo, fork, dy):
-                if ctx.zero_bias_grad:
-                    # the conv feeds a train-mode BatchNorm: the batch mean absorbs the bias, its gradient is exactly 0
-                    db = _empty((Cout,), x) if ctx.slots[1] is None else ctx.slots[1]
-                    _k("vmtl_fill_zero", p=db, n=Cout)
-                else:
-                    db = _colsum(dy, None, B * Ho * Wo, Cout, ldy, out=ctx.slots[1])
-            if ctx.slots[1] is not None:
-                db = None
+            db = _bias_grad(ctx.bias, ctx.slots[1], dy, B * Ho * Wo, Cout, ldy, ctx.zero_bias_grad, fork)
         return dx, dw, db, None, None, None, None
 
 
@@ -575,6 +593,7 @@ class _BNActPw(torch.autograd.Function):
         ctx.save_for_backward(x, a, weight, mean, invstd, gamma, beta)
         ctx.cfg = (C, training, act, bias is not None, bool(zero_bias_grad), res is not None)
         ctx.slots = (_slot(gamma), _slot(beta), _slot(weight), _slot(bias))
+        ctx.bias = bias
         ctx.set_materialize_grads(False)
         if ostats is not None:
             ctx.mark_non_differentiable(ostats)
@@ -627,16 +646,11 @@ class _BNActPw(torch.autograd.Function):
             unpack(slabs, weight.shape, 1, Cout, 1, Cin, Cs, 0, Cin, 1, 1, out=dw, nslabs=ns)
         db = None
         if has_bias and ctx.needs_input_grad[9]:
-            with side.branch(sbias is not None, M, fork, dy):
-                if zero_bias:
-                    db = _empty((Cout,), x) if sbias is None else sbias
-                    _k("vmtl_fill_zero", p=db, n=Cout)
-                else:
-                    db = _colsum(dy, None, M, Cout, ldy, out=sbias)
+            db = _bias_grad(ctx.bias, sbias, dy, M, Cout, ldy, zero_bias, fork)
         nif = lambda g, slot: None if slot is not None else g
         # act = none with a residual: d(res) is the gradient w.r.t. a itself = dz (no activation derivative in it)
         dres = dz if has_res and ctx.needs_input_grad[10] else None
-        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), nif(db, sbias), dres, None
+        return dx, None, None, nif(dgamma, sg), nif(dbeta, sb), None, None, None, nif(dw, sw), db, dres, None
 
 
 _BN_PW_MAX_ROWS = int(os.environ.get("VMTL_BN_PW_MAX_ROWS", str(1 << 30)))
@@ -690,6 +704,7 @@ class _Conv1x1Cat(torch.autograd.Function):
         ctx.save_for_backward(xa, xb, weight)
         ctx.cfg = (Cb, bias is not None, bool(zero_bias_grad))
         ctx.slots = (_slot(weight), _slot(bias))
+        ctx.bias = bias
         ctx.set_materialize_grads(False)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -726,14 +741,7 @@ class _Conv1x1Cat(torch.autograd.Function):
                 unpack(slabs, None, 1, Cout, 1, Cin, Ks, 0, Cin, 1, 1, out=flat, nslabs=ns)
             dw = None if sw is not None else dwt
         if has_bias and ctx.needs_input_grad[3]:
-            with side.branch(sbias is not None, M, fork, dy):
-                if zero_bias:
-                    db = _empty((Cout,), xa) if sbias is None else sbias
-                    _k("vmtl_fill_zero", p=db, n=Cout)
-                else:
-                    db = _colsum(dy, None, M, Cout, ldy, out=sbias)
-            if sbias is not None:
-                db = None
+            db = _bias_grad(ctx.bias, sbias, dy, M, Cout, ldy, zero_bias, fork)
         return dxa, dxb, dw, db, None, None, None
 
 
@@ -1016,8 +1024,12 @@ def bn_act_conv(x, stats, rpb, bn, C, act, weight, skip=None, up2=False, want_st
 
 
 def up2_conv(xl, C0, skip, weight, want_stats=False):
-    """(y, stats) = conv3x3(cat[nearest_x2(xl), skip]); C0 = logical channels of xl; stats may be None."""
-    return _Up2Conv.apply(xl, skip, weight, C0, want_stats)
+    """(y, stats) = conv3x3(cat[nearest_x2(xl), skip]); C0 = logical channels of xl; stats may be None.  Like conv2d's, the
+    statistics rows carry the pixels each covers (`_vmtl_rpb`: the up2 tile picker's row block, not conv_pick_tile's)."""
+    y, stats = _Up2Conv.apply(xl, skip, weight, C0, want_stats)
+    if stats is not None:
+        stats._vmtl_rpb = lib().raw("vmtl_conv2d_up2_stats_block")(xl.shape[0], xl.shape[1], xl.shape[2], y.shape[3])
+    return y, stats
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False, zero_bias_grad=False):
@@ -1653,14 +1665,14 @@ class _ToNCHW(torch.autograd.Function):
         y = _empty((B, C, H, W), x)
         _k("vmtl_nhwc_to_nchw", x=x, y=y, B=B, C=C, HW=H * W, Cs=Cs)
         ctx.Cs = Cs
+        _remember_mode(ctx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         B, C, H, W = dy.shape
         ld = ctx.Cs
-        if side.task_mode:  # first backward node of a task network: its stream is joined when the engine is done
-            side.join_at_end_of_backward()
+        _restore_mode(ctx)  # first backward node of a (task) network
         if (dy.is_cuda and dy.dtype == torch.float32 and dy.stride() == (H * W * ld, 1, W * ld, ld) and dy.storage_offset() == 0
                 and dy.untyped_storage().nbytes() == 4 * B * H * W * ld and getattr(dy, "_vmtl_nhwc", None) is not None):
             # the cross-entropy backward already wrote this gradient as NHWC rows of exactly our width, pad lanes zero
@@ -1759,12 +1771,14 @@ class _DecoderTail(torch.autograd.Function):
         ctx.save_for_backward(x1, a1, x2, a2, mean1, invstd1, mean2, invstd2, g1, b1, g2, b2, w2, wa, wb)
         ctx.cfg = (tr1, tr2)
         ctx.slots = tuple(_slot(t) for t in (g1, b1, w2, g2, b2, wa, ba, wb, bb))
+        _remember_mode(ctx)
         return oa, ob
 
     @staticmethod
     def backward(ctx, ga, gb):
         x1, a1, x2, a2, mean1, invstd1, mean2, invstd2, g1, b1, g2, b2, w2, wa, wb = ctx.saved_tensors
         tr1, tr2 = ctx.cfg
+        _restore_mode(ctx)
         sg1, sb1, sw2, sg2, sb2, swa, sba, swb, sbb = ctx.slots
         B, H, W, Cs1 = x1.shape
         C2, C1 = w2.shape[0], w2.shape[1]
@@ -1900,12 +1914,14 @@ class _DualHead(torch.autograd.Function):
         ctx.save_for_backward(x, wa, wb)
         ctx.cfg = (pad, ldy)
         ctx.slots = (_slot(wa), _slot(ba), _slot(wb), _slot(bb))
+        _remember_mode(ctx)
         return oa, ob
 
     @staticmethod
     def backward(ctx, ga, gb):
         x, wa, wb = ctx.saved_tensors
         pad, ldy = ctx.cfg
+        _restore_mode(ctx)
         B, H, W, Cs = x.shape
         Ca, Cin, KH, KW = wa.shape
         Cb = wb.shape[0]
@@ -1971,27 +1987,33 @@ def sigmoid(x):
 
 
 class _Fork(torch.autograd.Function):
-    """Two handles on one tensor for its two consumers (a block's residual branch and its first conv, an encoder
-    feature and the next stage).  Autograd would sum the two gradients with an ATen kernel; here the sum is a
-    launch of this library (vmtl_eltwise), so the step runs no kernel the C ABI does not export."""
+    """n handles on one tensor for its n consumers (a block's residual branch and its first conv, an encoder feature and
+    the next stage; MTAN's shared features feed the shared path AND both task attention modules: reference
+    models/mtan_model.py:364-399).  Autograd would sum the gradients with n-1 ATen kernels; here the sum is ONE launch
+    of this library (vmtl_add_n, up to 4 operands per launch), so the step runs no kernel the C ABI does not export."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, n):
         ctx.set_materialize_grads(False)  # an unused handle contributes None, not a zero tensor to add
-        return x.detach(), x.detach()
+        return tuple(x.detach() for _ in range(n))
 
     @staticmethod
-    def backward(ctx, g1, g2):
-        if g1 is None or g2 is None:
-            return g1 if g2 is None else g2
-        g1, g2 = _req(g1, "grad"), _req(g2, "grad")
-        out = _empty(g1.shape, g1)
-        _k("vmtl_eltwise", a=g1, b=g2, y=out, mode=0, total=g1.numel())
-        return out
+    def backward(ctx, *gs):
+        gs = [_req(g, "grad") for g in gs if g is not None]
+        if not gs:
+            return None, None
+        while len(gs) > 1:
+            k = min(4, len(gs))
+            ops4 = gs[:k] + [None] * (4 - k)
+            out = _empty(gs[0].shape, gs[0])
+            _k("vmtl_add_n", a=ops4[0], b=ops4[1], c=ops4[2], d=ops4[3], y=out, total=out.numel())
+            gs = [out] + gs[k:]
+        return gs[0], None
 
 
-def fork(x):
-    return _Fork.apply(x)
+def fork(x, n=2):
+    """n independent handles on x (gradients summed by this library's kernel)."""
+    return _Fork.apply(x, n)
 
 
 class _AddScalars(torch.autograd.Function):
