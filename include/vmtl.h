@@ -50,9 +50,11 @@ int vmtl_timestamp(long long* out, void* stream);
 int vmtl_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats,
                     int B, int H, int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout,
                     int KH, int KW, int stride, int pad, int act, int shuffle, void* stream);
-/* split-K form for plain contractions (data gradients): ws = vmtl_conv2d_ksplit(...)*B*Ho*Wo*ldy floats */
+/* split-K form for contractions without activation / statistics / shuffle (data gradients, and forward convs of
+ * tile-starved layers - decoder blocks 0-1 at small batch - whose BatchNorm then takes its statistics from a sweep):
+ * ws = vmtl_conv2d_ksplit(...)*B*Ho*Wo*ldy floats; bias (nullable) is added by the slab sum */
 int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot);
-int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int B, int H, int W, int Cs,
+int vmtl_conv2d_fwd_ws(const float* x, const float* wp, const float* bias, float* y, float* ws, int B, int H, int W, int Cs,
                        int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride, int pad, void* stream);
 int vmtl_conv2d_stats_rows(int B, int Ho, int Wo, int ldy);
 int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per stats row block */
@@ -112,6 +114,10 @@ int vmtl_conv2d_bnbwd(const float* x, const float* wp, float* y, float* stats, c
 int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const float* wp_eff, float* y, float* stats,
                         int B, int H2, int W2, int C0s, int C1s, int ldy, int Cout, void* stream);
 int vmtl_conv2d_up2_stats_block(int B, int H2, int W2, int ldy);
+/* split-K form of vmtl_conv2d_up2_fwd (no statistics): ws = vmtl_conv2d_up2_ksplit(...)*B*2H2*2W2*ldy floats */
+int vmtl_conv2d_up2_ksplit(int B, int H2, int W2, int ldy, int Ktot);
+int vmtl_conv2d_up2_fwd_ws(const float* xl, const float* skip, const float* wp_eff, float* y, float* ws, int B, int H2,
+                           int W2, int C0s, int C1s, int ldy, int Cout, void* stream);
 int vmtl_pack_up2_fwd(const float* w, float* dst, int Cout, int C0, int C0s, int C1, int C1s, void* stream);
 int vmtl_pack_up2_dgrad(const float* w, float* dst, int Cout, int Cos, int C0, int Cin, void* stream);
 int vmtl_unpack_up2(const float* slabs, float* grad, int Cout, int Cos, int C0, int Cin, int nslabs, void* stream);

@@ -58,6 +58,7 @@ def test_arena_slots_side_stream_and_graph(dev, name):
             # every slot must be overwritten, not accumulated into (CSNet: the off-diagonal stitch entries are
             # never written and keep the arena's initial zero, as their reference gradient is zero)
             arena.flat_grad.fill_(0.0 if name == "csnet" else float("nan"))
+            arena.slots_clobbered()  # written behind the arena's back: structurally-zero slots get re-zeroed
             loss = step()
             torch.cuda.synchronize()
             assert ops.side.pending is None
@@ -72,6 +73,11 @@ def test_arena_slots_side_stream_and_graph(dev, name):
             static_loss = step()
         for _ in range(2):
             arena.flat_grad.fill_(0.0 if name == "csnet" else float("nan"))
+            # slots the arena KNOWS to be zero (biases in front of a train-mode BatchNorm, ops._bias_grad) are not
+            # rewritten by the captured step: keep their zero, poison everything else
+            for p in arena.params:
+                if id(p) in arena._zero_bias:
+                    p._vmtl_gslot.zero_()
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(static_loss, loss_ref)

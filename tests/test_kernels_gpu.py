@@ -66,14 +66,17 @@ def test_conv2d_fwd_bwd(dev, case):
 
     Ho, Wo = yr.shape[2], yr.shape[3]
     M = B * Ho * Wo
-    rpb = stats._vmtl_rpb  # pixels per statistics row (the launch's row block: implicit GEMM or pointwise kernel)
-    st = stats.double().cpu()
-    nb = torch.tensor([max(0, min(rpb, M - b * rpb)) for b in range(st.shape[0])], dtype=torch.float64)[:, None]
-    mean = (nb * st[:, 0]).sum(0) / M
-    var = (st[:, 1] + nb * (st[:, 0] - mean) ** 2).sum(0) / M
-    yo = yr.detach().double()
-    assert_close(mean[:Cout], yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="conv stats mean")
-    assert_close(var[:Cout], yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="conv stats var")
+    if stats is None:  # a tile-starved shape runs split-K: no statistics epilogue, the BatchNorm sweeps y itself
+        assert ops.conv_ksplit(B, Ho, Wo, xd.shape[-1], y.shape[-1], K, K, stride, pad) > 1
+    else:
+        rpb = stats._vmtl_rpb  # pixels per statistics row (the launch's row block: implicit GEMM or pointwise kernel)
+        st = stats.double().cpu()
+        nb = torch.tensor([max(0, min(rpb, M - b * rpb)) for b in range(st.shape[0])], dtype=torch.float64)[:, None]
+        mean = (nb * st[:, 0]).sum(0) / M
+        var = (st[:, 1] + nb * (st[:, 0] - mean) ** 2).sum(0) / M
+        yo = yr.detach().double()
+        assert_close(mean[:Cout], yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="conv stats mean")
+        assert_close(var[:Cout], yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="conv stats var")
     y.backward(to_dev_nhwc(gy, dev))
     assert_close(wd.grad.cpu(), wr.grad, what="conv wgrad")
     if need_dx:
@@ -267,6 +270,44 @@ def _check_up2(dev, case):
     assert_close(wd.grad.cpu(), wr.grad, what="up2 dw")
     if C1:
         assert_close(from_dev_nhwc(skd.grad, C1), skr.grad, what="up2 dskip")
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_conv2d_forward_split_k(dev, bias):
+    """Tile-starved forward convs (decoder blocks 0-1 at small batch) run as K slices + a slab sum that also adds the
+    bias; they hand back no statistics rows.  Values, pad zeros and all gradients against torch."""
+    ops = _ops()
+    B, Cin, H, W, Cout = 2, 130, 12, 12, 70
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    ref = [t.clone().requires_grad_(True) for t in (x, w)] + ([b.clone().requires_grad_(True)] if bias else [])
+    yr = F.conv2d(ref[0], ref[1], ref[2] if bias else None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    assert ops.conv_ksplit(B, H, W, xd.shape[-1], 72, 3, 3, 1, 1) > 1
+    y, stats = ops.conv2d(xd, wd, bd, stride=1, pad=1, want_stats=True)
+    assert stats is None
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="split-K fwd")
+    assert y[..., Cout:].abs().max().item() == 0.0
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, Cin), ref[0].grad, what="split-K dgrad")
+    assert_close(wd.grad.cpu(), ref[1].grad, what="split-K wgrad")
+    if bias:
+        assert_close(bd.grad.cpu(), ref[2].grad, what="split-K bias grad")
+
+
+def test_up2_conv_split_k(dev):
+    """The phase-decomposed decoder-block entry with its K loop split over workgroups (deep blocks at small batch)."""
+    from vision_mtl_amd._lib import lib
+
+    case = (1, 240, 40, 6, 8, 70)
+    assert lib().raw("vmtl_conv2d_up2_ksplit")(1, 6, 8, 72, 4 * 240 + 9 * 40) > 1
+    _check_up2(dev, case)
 
 
 def test_dual_head(dev):

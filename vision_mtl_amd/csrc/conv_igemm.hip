@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // ---- epilogue: bias + activation, zero the pad channels, store ----
   // C layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int hw = p.Ho * p.Wo;
-  float* yout = p.ksplit > 1 ? p.y + (size_t)blockIdx.y * p.M * p.ldy : p.y;
+  // split-K: slice blockIdx.y writes its partial tile into its own slab (UP2: a slab has the full-resolution layout)
+  float* yout = p.ksplit > 1 ? p.y + (size_t)blockIdx.y * (UP2 ? 4 : 1) * p.M * p.ldy : p.y;
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             if (n >= p.Cout) v = 0.f;
             const int b_ = m / hw, rem = m - b_ * hw;
             const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
-            p.y[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
+            yout[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
           }
         } else if (!p.shuffle) {
           if (n < p.ldy) {
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           if (UP2) {
             const int b_ = m / hw, rem = m - b_ * hw;
             const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
-            p.y[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
+            yout[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
           } else {
             yout[(size_t)m * p.ldy + n] = v;
           }
@@ -746,20 +747,23 @@ struct WgradP {
 
 // smallest row stride >= w (floats, multiple of 4) that is == 16 (mod 64): the four pixel rows of one fragment read
 // start 16 banks apart whether the hardware serves the 64 lanes over 64 banks at once or as two 32-lane groups over 32
-__host__ __device__ constexpr int wg_ld(int w) { return ((w + 47) / 64) * 64 + 16; }
+// PM (tuning aid VMTL_WG_PAD, A/B on the GPU box): 0 = round 2's width + 4, 1 = == 16 (mod 64), 2 = == 16 (mod 32)
+__host__ __device__ constexpr int wg_ld(int w, int pm = 1) {
+  return pm == 0 ? w + 4 : pm == 1 ? ((w + 47) / 64) * 64 + 16 : ((w + 15) / 32) * 32 + 16;
+}
 static_assert(wg_ld(16) == 16 && wg_ld(20) == 80 && wg_ld(144) == 144 && wg_ld(128) == 144 && wg_ld(68) == 80 &&
-              wg_ld(80) == 80 && wg_ld(84) == 144, "wg_ld");
+              wg_ld(80) == 80 && wg_ld(84) == 144 && wg_ld(36, 2) == 48 && wg_ld(128, 2) == 144, "wg_ld");
 
 // co rows per workgroup = TM * 16 (+ NTR "tail" rows: the 33rd / 17-20th / 65-68th output channel is not
 // given an MFMA tile of its own - each lane multiplies its X fragment with the tail dY values on the VALU,
 // the same trick as the tail columns of conv_igemm_kernel); waves are laid out 1 x 4 along kk
-template <int TM, int NTR = 0>
+template <int TM, int NTR = 0, int PM = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int TN = 2;
   constexpr int BMM = TM * 16;    // rows covered by MFMA tiles
   constexpr int BMC = BMM + NTR;  // + tail rows
-  constexpr int LDY = wg_ld(BMC);
-  constexpr int LDX = wg_ld(WG_BNK);
+  constexpr int LDY = wg_ld(BMC, PM);
+  constexpr int LDX = wg_ld(WG_BNK, PM);
   constexpr int YQ = BMC / 4;                 // float4 per dY row
   constexpr int YIT = (BP * YQ + 255) / 256;  // loader iterations for the dY tile
   constexpr int XQ = WG_BNK / 4;              // 32 float4 per X row
@@ -1068,11 +1072,19 @@ static int launch_conv_ns(ConvP& p, hipStream_t st) {
   return vmtl_check_launch();
 }
 
+// y = sum of the K-slice slabs (+ bias[n], n = column of a [rows][ldy] matrix; pad columns n >= Cout stay 0)
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ y,
-                                                        int nslabs, long long n4) {
+                                                        int nslabs, long long n4, const float* __restrict__ bias,
+                                                        int ldy, int Cout) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
     for (int z = 1; z < nslabs; ++z) s += reinterpret_cast<const f32x4*>(slabs)[(size_t)z * n4 + i];
+    if (bias != nullptr) {
+      const int n = (int)((i * 4) % ldy);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < Cout) s[e] += bias[n + e];
+    }
     reinterpret_cast<f32x4*>(y)[i] = s;
   }
 }
@@ -1080,16 +1092,23 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
 // K slices a forward/dgrad launch of this shape would use (1 = none).  Only launches without
 // bias/activation/stats/shuffle are split; the caller then passes a workspace of
 // splits * B*Ho*Wo * ldy floats (vmtl_conv2d_fwd_ws) and the partial tiles are summed in slice order.
-extern "C" int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot) {
-  const int M = B * Ho * Wo;
-  const int id = conv_pick_tile(M, ldy);
-  const long long blocks = (long long)cdiv(M, kTiles[id].bm) * cdiv(ldy, kTiles[id].bn);
-  const int nk = cdiv(Ktot, BK);
-  if (blocks >= 256 || nk < 32 || (ldy & 3)) return 1;
-  long long s = cdivll(512, blocks);
+// K slices for a tile grid of `blocks` workgroups and nk K steps: split while the grid alone leaves the chip under-filled
+// (fewer than VMTL_KSPLIT_BLOCKS workgroups, default 512 = two per CU: one 4-wave workgroup per CU is one wave per SIMD
+// and hides no latency - decoder block 0 at bs 32 ran at 82 TF on 256 workgroups), at least 16 K steps per slice
+static int ksplit_for(long long blocks, int nk, int ldy) {
+  static EnvInt e_blocks{"VMTL_KSPLIT_BLOCKS", 512};  // tuning aid
+  const int target = env_int(e_blocks);
+  if (blocks >= target || nk < 32 || (ldy & 3)) return 1;
+  long long s = cdivll(target, blocks);
   if (s > 8) s = 8;
   if (s > nk / 16) s = nk / 16;
   return s < 2 ? 1 : (int)s;
+}
+
+extern "C" int vmtl_conv2d_ksplit(int B, int Ho, int Wo, int ldy, int Ktot) {
+  const int M = B * Ho * Wo;
+  const int id = conv_pick_tile(M, ldy);
+  return ksplit_for((long long)cdiv(M, kTiles[id].bm) * cdiv(ldy, kTiles[id].bn), cdiv(Ktot, BK), ldy);
 }
 
 static int conv2d_fwd_impl(const float* x, const float* wp, const float* bias, float* y, float* stats,
@@ -1157,13 +1176,13 @@ extern "C" int vmtl_conv2d_bnbwd(const float* x, const float* wp, float* y, floa
 
 // split-K form of vmtl_conv2d_fwd for plain contractions (no bias / act / stats / shuffle): `ws` holds
 // vmtl_conv2d_ksplit(...) * B*Ho*Wo*ldy floats.  With ksplit == 1 it is exactly vmtl_conv2d_fwd.
-extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, float* ws, int B, int H, int W, int Cs,
-                                  int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride, int pad,
-                                  void* stream) {
+extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, const float* bias, float* y, float* ws, int B, int H,
+                                  int W, int Cs, int Ho, int Wo, int ldy, int Nw, int Cout, int KH, int KW, int stride,
+                                  int pad, void* stream) {
   VMTL_ENTER();
   const int splits = vmtl_conv2d_ksplit(B, Ho, Wo, ldy, KH * KW * Cs);
   if (splits <= 1 || ws == nullptr)
-    return vmtl_conv2d_fwd(x, wp, nullptr, y, nullptr, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, 0, 0, stream);
+    return vmtl_conv2d_fwd(x, wp, bias, y, nullptr, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, KW, stride, pad, 0, 0, stream);
   if (!x || !wp || !y || Cs <= 0 || (Cs & 3) || Nw > ldy || Cout > ldy) return VMTL_ERR_ARG;
   if ((H + 2 * pad - KH) / stride + 1 != Ho || (W + 2 * pad - KW) / stride + 1 != Wo) return VMTL_ERR_ARG;
   ConvP p;
@@ -1197,7 +1216,7 @@ extern "C" int vmtl_conv2d_fwd_ws(const float* x, const float* wp, float* y, flo
   const long long n4 = (long long)p.M * ldy / 4;
   long long nb = cdivll(n4, 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(sum_slabs_kernel, dim3((int)nb), dim3(256), 0, st, ws, y, splits, n4);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((int)nb), dim3(256), 0, st, ws, y, splits, n4, bias, ldy, Cout);
   return vmtl_check_launch();
 }
 
@@ -1224,6 +1243,16 @@ extern "C" int vmtl_conv2d_up2_stats_block(int B, int H2, int W2, int ldy) {
   return kTiles[up2_pick_tile(B * H2 * W2, ldy)].bm;
 }
 
+// K slices of the phase-decomposed conv for this shape (1 = none): the deep decoder blocks at small batch are a few dozen
+// workgroups with a K loop of 80-150 steps (decoder block 0 at bs 8: 64 workgroups, 21 TF before)
+extern "C" int vmtl_conv2d_up2_ksplit(int B, int H2, int W2, int ldy, int Ktot) {
+  const int Mq = B * H2 * W2;
+  const int id = up2_pick_tile(Mq, ldy);
+  return ksplit_for((long long)cdiv(Mq, kTiles[id].bm) * 4 * cdiv(ldy, kTiles[id].bn), cdiv(Ktot, BK), ldy);
+}
+
+static int up2_launch(ConvP& p, int id, hipStream_t st);
+
 // stats (optional): [4 * ceil(B*H2*W2 / block)][2][ldy]; only valid when block divides B*H2*W2
 extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const float* wp_eff, float* y, float* stats,
                                    int B, int H2, int W2, int C0s, int C1s, int ldy, int Cout, void* stream) {
@@ -1240,7 +1269,38 @@ extern "C" int vmtl_conv2d_up2_fwd(const float* xl, const float* skip, const flo
   p.ez_x = nullptr; p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = nullptr; p.ez_act = 0;
   const int id = up2_pick_tile(p.M, ldy);
   if (stats && (p.M % kTiles[id].bm)) return VMTL_ERR_ARG;
+  return up2_launch(p, id, (hipStream_t)stream);
+}
+
+// split-K form (no statistics): ws = vmtl_conv2d_up2_ksplit(...) * B*2H2*2W2*ldy floats; the slices' partial outputs
+// (full-resolution layout each) are summed in slice order
+extern "C" int vmtl_conv2d_up2_fwd_ws(const float* xl, const float* skip, const float* wp_eff, float* y, float* ws, int B,
+                                      int H2, int W2, int C0s, int C1s, int ldy, int Cout, void* stream) {
+  VMTL_ENTER();
+  const int splits = vmtl_conv2d_up2_ksplit(B, H2, W2, ldy, 4 * C0s + 9 * C1s);
+  if (splits <= 1 || ws == nullptr)
+    return vmtl_conv2d_up2_fwd(xl, skip, wp_eff, y, nullptr, B, H2, W2, C0s, C1s, ldy, Cout, stream);
+  if (!xl || !wp_eff || !y || B <= 0 || H2 <= 0 || W2 <= 0 || C0s <= 0 || (C0s & 3) || (C1s & 3) || C1s < 0)
+    return VMTL_ERR_ARG;
+  if ((skip == nullptr) != (C1s == 0) || Cout <= 0 || Cout > ldy || (ldy & 3)) return VMTL_ERR_ARG;
+  if ((long long)B * H2 * W2 * 4 > 0x7fffffffLL) return VMTL_ERR_ARG;
+  ConvP p;
+  p.x = xl; p.x2 = skip; p.wp = wp_eff; p.bias = nullptr; p.y = ws; p.stats = nullptr;
+  p.B = B; p.H = H2; p.W = W2; p.Cs = C0s; p.C2s = C1s; p.Ho = H2; p.Wo = W2; p.ldy = ldy; p.Nw = Cout;
+  p.Cout = Cout; p.KH = 2; p.KW = 2; p.stride = 1; p.pad = 0; p.Ktot = 4 * C0s + 9 * C1s; p.M = B * H2 * W2;
+  p.act = 0; p.shuffle = 0; p.ksplit = splits; p.ksteps_per_split = cdiv(cdiv(p.Ktot, BK), splits);
+  p.ez_x = nullptr; p.ez_mean = p.ez_invstd = p.ez_gamma = p.ez_beta = nullptr; p.ez_act = 0;
   hipStream_t st = (hipStream_t)stream;
+  const int rc = up2_launch(p, up2_pick_tile(p.M, ldy), st);
+  if (rc) return rc;
+  const long long n4 = (long long)4 * p.M * ldy / 4;
+  long long nb = cdivll(n4, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((int)nb), dim3(256), 0, st, ws, y, splits, n4, (const float*)nullptr, ldy, Cout);
+  return vmtl_check_launch();
+}
+
+static int up2_launch(ConvP& p, int id, hipStream_t st) {
   switch (id) {
     case 0: return launch_conv<2, 2, 4, 1, true>(p, st);
     case 1: return launch_conv<2, 3, 4, 1, true>(p, st);
@@ -1309,13 +1369,41 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   return cdiv(M, chunk);
 }
 
+template <int TM, int NTR, int PM>
+static int launch_wgrad_pm(WgradP& p, int splits, hipStream_t st);
+
+// Stride rule per tile height.  Measured on MI355X (tools/bench_conv.py, VMTL_WG_PAD A/B, round 3): the conflict-free
+// strides remove ALL bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.425 -> 0.000 on the 144-row tile)
+// but change the kernel's time by < 1 % - it is not LDS-bound - while every workgroup per CU lost to the larger tiles
+// costs 10-20 % (68 rows: 517 -> 589 us, 36 rows: 562 -> 665 us).  So: the conflict-free stride wherever it keeps the
+// workgroups per CU (160 KB LDS), round 2's width + 4 elsewhere.
+template <int BMC>
+constexpr int wg_pm() {
+  constexpr int base = 160 * 1024 / (2 * BP * (wg_ld(BMC, 0) + wg_ld(WG_BNK, 0)) * 4);
+  return 160 * 1024 / (2 * BP * (wg_ld(BMC, 1) + wg_ld(WG_BNK, 1)) * 4) >= base   ? 1
+         : 160 * 1024 / (2 * BP * (wg_ld(BMC, 2) + wg_ld(WG_BNK, 2)) * 4) >= base ? 2
+                                                                                    : 0;
+}
+static_assert(wg_pm<144>() == 1 && wg_pm<80>() == 1 && wg_pm<36>() == 2 && wg_pm<68>() == 0 && wg_pm<20>() == 0, "wg_pm");
+
 template <int TM, int NTR = 0>
 static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
+  static EnvInt e_pad{"VMTL_WG_PAD", -1};  // tuning aid: force one LDS row-stride rule (wg_ld) for every tile height
+  switch (env_int(e_pad)) {
+    case 0: return launch_wgrad_pm<TM, NTR, 0>(p, splits, st);
+    case 1: return launch_wgrad_pm<TM, NTR, 1>(p, splits, st);
+    case 2: return launch_wgrad_pm<TM, NTR, 2>(p, splits, st);
+    default: return launch_wgrad_pm<TM, NTR, wg_pm<TM * 16 + NTR>()>(p, splits, st);
+  }
+}
+
+template <int TM, int NTR, int PM>
+static int launch_wgrad_pm(WgradP& p, int splits, hipStream_t st) {
   constexpr int BMC = TM * 16 + NTR;
-  const size_t lds = (size_t)2 * BP * (wg_ld(BMC) + wg_ld(WG_BNK)) * sizeof(float);
+  const size_t lds = (size_t)2 * BP * (wg_ld(BMC, PM) + wg_ld(WG_BNK, PM)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, NTR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, NTR, PM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1324,7 +1412,7 @@ static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
   p.tiles_kk = cdiv(p.Ktot, WG_BNK);
   p.tiles_co = cdiv(p.Nw, BMC);
   p.splits = splits;
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM, NTR>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, NTR, PM>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st, p);
   return vmtl_check_launch();
 }
 

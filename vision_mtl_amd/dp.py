@@ -56,7 +56,7 @@ class FlatArena:
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.params, self.offsets, off = params, [], 0
         self._kernel_written = set()  # ids of parameters whose slot a HIP backward kernel writes (ops._slot); per step
-        self._nonzero_bias = set()    # ids of bias parameters whose slot holds column sums (see ops._bias_grad)
+        self._zero_bias = set()       # ids of bias parameters whose slot is KNOWN to hold zeros (see ops._bias_grad)
         self._scale_consumer = None   # weak reference to the ArenaAdam that folds pending_scale into its update
         self._hooks = []
         for p in params:
@@ -140,7 +140,11 @@ class FlatArena:
         """One memset of the whole gradient buffer (slots written by kernels do not need it: they are overwritten)."""
         self.flat_grad.zero_()
         self.pending_scale = 1.0
-        self._nonzero_bias.clear()
+
+    def slots_clobbered(self) -> None:
+        """Tell the arena that flat_grad was written from outside (a test poisoning it, a checkpoint restore): slots
+        whose gradient is structurally zero are then zeroed again by the next backward pass instead of being trusted."""
+        self._zero_bias.clear()
 
     def rebind_grads(self) -> None:
         """Re-attach every parameter's .grad to its arena slot (after an optimizer.zero_grad(set_to_none=True), torch

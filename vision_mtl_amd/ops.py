@@ -427,27 +427,27 @@ def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
 
 def _bias_grad(bias, slot, dy, M, Cout, ldy, zero, fork):
     """dL/dbias of a conv (column sums of dy), into its arena slot when there is one (returns None then).
-    zero: the conv feeds a TRAIN-mode BatchNorm - the batch mean absorbs the bias, its gradient is exactly 0.  An arena
-    slot is zero from the arena's construction / zero_grad() on and this is its only writer, so nothing is launched
-    unless an earlier (eval-mode BatchNorm) step left column sums there (FlatArena._nonzero_bias keeps track): MTAN's 56
-    attention-conv biases cost 56 memset launches per step before."""
+    zero: the conv feeds a TRAIN-mode BatchNorm - the batch mean absorbs the bias, its gradient is exactly 0.  This
+    function is the slot's only writer, so the zero is written ONCE (first backward pass) and remembered
+    (FlatArena._zero_bias); later steps launch nothing - MTAN's 56 attention-conv biases cost 56 memset launches per step
+    before.  Column sums written later (an eval-mode BatchNorm step) or FlatArena.slots_clobbered() forget it."""
     arena = getattr(bias, "_vmtl_arena", None) if slot is not None else None
     if zero:
         if slot is None:
             db = _empty((Cout,), dy)
             _k("vmtl_fill_zero", p=db, n=Cout)
             return db
-        if arena is None or id(bias) in arena._nonzero_bias:
+        if arena is None or id(bias) not in arena._zero_bias:
             with side.branch(True, M, fork, dy):
                 _k("vmtl_fill_zero", p=slot, n=Cout)
-            if arena is not None:
-                arena._nonzero_bias.discard(id(bias))
+            if arena is not None and not torch.cuda.is_current_stream_capturing():
+                arena._zero_bias.add(id(bias))
         return None
     with side.branch(slot is not None, M, fork, dy):
         db = _colsum(dy, None, M, Cout, ldy, out=slot)
     if slot is not None:
         if arena is not None:
-            arena._nonzero_bias.add(id(bias))
+            arena._zero_bias.discard(id(bias))
         return None
     return db
 
@@ -459,6 +459,14 @@ _PW_MAX_ROWS = int(os.environ.get("VMTL_PW_MAX_ROWS", str(1 << 21)))  # measured
 
 def _is_pw(B, Ho, Wo, KH, KW, stride, pad, shuffle=0):
     return _PW and KH == 1 and KW == 1 and stride == 1 and pad == 0 and not shuffle and B * Ho * Wo <= _PW_MAX_ROWS
+
+
+def conv_ksplit(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad, shuffle=0) -> int:
+    """K slices a dense conv launch of this shape runs as (1 = none).  A split launch has no statistics epilogue: the
+    BatchNorm that follows takes its statistics from its own sweep of the (small) output instead."""
+    if shuffle or _is_pw(B, Ho, Wo, KH, KW, stride, pad, shuffle):
+        return 1
+    return lib().raw("vmtl_conv2d_ksplit")(B, Ho, Wo, ldy, KH * KW * Cs)
 
 
 def conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad):
@@ -476,13 +484,14 @@ def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, 
         _k("vmtl_conv1x1_fwd", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y,
            stats=stats, M=B * Ho * Wo, Ks=Cs, ldy=ldy, Nw=Nw, Cout=Cout)
         return
-    if bias is None and stats is None and not shuffle:
-        # plain contraction (data gradients): split K when the tile grid alone cannot fill the chip
+    if stats is None and not shuffle:
+        # contraction without a statistics epilogue (data gradients; forward convs of tile-starved layers, see
+        # conv_ksplit): split K when the tile grid alone cannot fill the chip
         ks = lib().raw("vmtl_conv2d_ksplit")(B, Ho, Wo, ldy, KH * KW * Cs)
         if ks > 1:
             ws = _empty((ks, B * Ho * Wo, ldy), x)
-            _k("vmtl_conv2d_fwd_ws", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, y=y, ws=ws,
-               B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad)
+            _k("vmtl_conv2d_fwd_ws", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y,
+               ws=ws, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy, Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad)
             return
     _k("vmtl_conv2d_fwd", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y, stats=stats, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo, ldy=ldy,
        Nw=Nw, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act=0, shuffle=shuffle)
@@ -507,6 +516,8 @@ class _Conv2d(torch.autograd.Function):
         wp = packs.get(weight, "fwd", (1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, 0))
         y = _empty((B, Ho, Wo, ldy), x)
         stats = None
+        if want_stats and conv_ksplit(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad) > 1:
+            want_stats = False  # tile-starved layer: split K, the BatchNorm sweeps the (small) output itself
         if want_stats:
             rows, _ = conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad)
             stats = _empty((rows, 2, ldy), x)
@@ -788,15 +799,21 @@ class _Up2Conv(torch.autograd.Function):
             "vmtl_pack_up2_fwd", w=w, dst=dst, Cout=Cout, C0=C0, C0s=C0s, C1=C1, C1s=C1s))
         y = _empty((B, 2 * H2, 2 * W2, ldy), xl)
         stats = None
-        if want_stats:
-            bm = lib().raw("vmtl_conv2d_up2_stats_block")(B, H2, W2, ldy)
-            Mq = B * H2 * W2
-            if Mq % bm == 0:
-                stats = _empty((4 * (Mq // bm), 2, ldy), xl)
         M = B * 4 * H2 * W2
         # algorithmic FLOPs = the reference formulation (9 taps on every channel); executed: 4 taps on xl's
-        _k("vmtl_conv2d_up2_fwd", _flop=2.0 * M * Cout * 9 * Cin, _xflop=2.0 * M * Cout * (4 * C0 + 9 * C1), xl=xl,
-           skip=skip, wp_eff=wp, y=y, stats=stats, B=B, H2=H2, W2=W2, C0s=C0s, C1s=C1s, ldy=ldy, Cout=Cout)
+        ks = lib().raw("vmtl_conv2d_up2_ksplit")(B, H2, W2, ldy, Ktot)
+        if ks > 1:  # tile-starved (deep decoder blocks at small batch): split K, no statistics epilogue
+            _k("vmtl_conv2d_up2_fwd_ws", _flop=2.0 * M * Cout * 9 * Cin, _xflop=2.0 * M * Cout * (4 * C0 + 9 * C1), xl=xl,
+               skip=skip, wp_eff=wp, y=y, ws=_empty((ks, B, 2 * H2, 2 * W2, ldy), xl), B=B, H2=H2, W2=W2, C0s=C0s, C1s=C1s,
+               ldy=ldy, Cout=Cout)
+        else:
+            if want_stats:
+                bm = lib().raw("vmtl_conv2d_up2_stats_block")(B, H2, W2, ldy)
+                Mq = B * H2 * W2
+                if Mq % bm == 0:
+                    stats = _empty((4 * (Mq // bm), 2, ldy), xl)
+            _k("vmtl_conv2d_up2_fwd", _flop=2.0 * M * Cout * 9 * Cin, _xflop=2.0 * M * Cout * (4 * C0 + 9 * C1), xl=xl,
+               skip=skip, wp_eff=wp, y=y, stats=stats, B=B, H2=H2, W2=W2, C0s=C0s, C1s=C1s, ldy=ldy, Cout=Cout)
         ctx.save_for_backward(xl, skip, weight)
         ctx.cfg = (C0, C1, stats.shape[0] if stats is not None else 0)
         ctx.slot = _slot(weight)
@@ -905,19 +922,25 @@ class _BNActConv(torch.autograd.Function):
             wp = packs.get_custom(weight, "up2_fwd", (4, Cout, Ktot), lambda w, dst: _k(
                 "vmtl_pack_up2_fwd", w=w, dst=dst, Cout=Cout, C0=C, C0s=Cs, C1=C1, C1s=C1s))
             y = _empty((B, 2 * H, 2 * W, ldy), x)
-            if want_stats:
-                bm = lib().raw("vmtl_conv2d_up2_stats_block")(B, H, W, ldy)
-                if M % bm == 0:
-                    ostats, orpb = _empty((4 * (M // bm), 2, ldy), x), bm
             Mo = 4 * M
-            _k("vmtl_conv2d_up2_fwd", _flop=2.0 * Mo * Cout * 9 * Cin, _xflop=2.0 * Mo * Cout * (4 * C + 9 * C1), xl=a,
-               skip=skip, wp_eff=wp, y=y, stats=ostats, B=B, H2=H, W2=W, C0s=Cs, C1s=C1s, ldy=ldy, Cout=Cout)
+            ks = lib().raw("vmtl_conv2d_up2_ksplit")(B, H, W, ldy, Ktot)
+            if ks > 1:  # tile-starved (deep decoder blocks at small batch): split K, no statistics epilogue
+                _k("vmtl_conv2d_up2_fwd_ws", _flop=2.0 * Mo * Cout * 9 * Cin, _xflop=2.0 * Mo * Cout * (4 * C + 9 * C1),
+                   xl=a, skip=skip, wp_eff=wp, y=y, ws=_empty((ks, B, 2 * H, 2 * W, ldy), x), B=B, H2=H, W2=W, C0s=Cs,
+                   C1s=C1s, ldy=ldy, Cout=Cout)
+            else:
+                if want_stats:
+                    bm = lib().raw("vmtl_conv2d_up2_stats_block")(B, H, W, ldy)
+                    if M % bm == 0:
+                        ostats, orpb = _empty((4 * (M // bm), 2, ldy), x), bm
+                _k("vmtl_conv2d_up2_fwd", _flop=2.0 * Mo * Cout * 9 * Cin, _xflop=2.0 * Mo * Cout * (4 * C + 9 * C1), xl=a,
+                   skip=skip, wp_eff=wp, y=y, stats=ostats, B=B, H2=H, W2=W, C0s=Cs, C1s=C1s, ldy=ldy, Cout=Cout)
         else:
             if Cin != C or skip is not None:
                 raise ValueError("bn_act_conv: weight expects x's channels (skip only with up2)")
             wp = packs.get(weight, "fwd", (1, Cout, 9, Cin, Cs, 0, Cin * 9, 1, 9, 0))
             y = _empty((B, H, W, ldy), x)
-            if want_stats:
+            if want_stats and conv_ksplit(B, H, W, Cs, ldy, 3, 3, 1, 1) == 1:
                 ostats = _empty((lib().raw("vmtl_conv2d_stats_rows")(B, H, W, ldy), 2, ldy), x)
                 orpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, ldy)
             _conv_launch(a, wp, None, y, ostats, B, H, W, Cs, H, W, ldy, Cout, Cout, 3, 3, 1, 1, cin=Cin)
