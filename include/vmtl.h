@@ -228,7 +228,8 @@ int vmtl_bn_bwd_finalize(const float* partial, int nblk, int M, int C, int Cs, f
 int vmtl_bn_bwd_apply(const float* x, const float* dz, const float* mean, const float* invstd, const float* gamma,
                       const float* sum_dz, const float* sum_dzx, float* dx, int M, int C, int Cs, int training,
                       void* stream);
-/* out[c] = sum_m a[m][c] (mode 0) or a*b (mode 1); reduce_all sums over channels too. */
+/* out[c] = sum_m a[m][c] (mode 0) or a*b (mode 1); reduce_all sums over channels too.
+ * partial: (vmtl_reduce_rows(M) + 1) * Cs floats of scratch */
 int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,
                 float* partial, float* out, void* stream);
 
@@ -274,7 +275,7 @@ int vmtl_channel_scale_add(const float* x, const float* s, const float* t, float
 /* models/cross_stitch_model.py:32-37 (diagonal of the 2x2 stitch matrix) */
 int vmtl_stitch(const float* x, const float* w, float* y, long long M, int C, int Cs, int wstride, void* stream);
 /* its backward in one sweep: dx (nullable) = w * dy, dw[c] = sum_m x*dy (reduce_all: one scalar);
- * partial: vmtl_reduce_rows(M) * Cs floats of scratch */
+ * partial: (vmtl_reduce_rows(M) + 1) * Cs floats of scratch */
 int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, float* dx, float* partial, float* dw, int M,
                     int C, int Cs, int wstride, int reduce_all, void* stream);
 /* mode 0 add, 1 sigmoid, 2 sigmoid-backward-from-output, 3 scale by *b */

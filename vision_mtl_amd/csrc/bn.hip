@@ -652,17 +652,33 @@ __global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                              int Cs, int reduce_all, float* out) {
+                                                              int Cs, float* out) {
   __shared__ double sh[4];
-  if (reduce_all) {  // a single scalar: sum over channels too (layer-wise stitch weight gradient)
-    double tot = 0.0;
-    for (int c = 0; c < C; ++c) tot += block_rows_sum(partial, nblk, 1, 0, Cs, c, sh);
-    if (threadIdx.x == 0) out[0] = (float)tot;
-    return;
-  }
   const int c = blockIdx.x;
   const double s = block_rows_sum(partial, nblk, 1, 0, Cs, c, sh);
   if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+// a single scalar: the sum over channels too (layer-wise stitch weight gradient).  The per-channel sums come from the
+// C-workgroup finalize above (round 2 had ONE workgroup walk all C columns serially: up to 960 dependent block
+// reductions on the critical path - csnet ran 1.6 ms/step slower layer-wise than channel-wise)
+__global__ __launch_bounds__(256) void sum_channels_kernel(const float* __restrict__ v, int C, float* out) {
+  __shared__ double sh[4];
+  double a = 0.0;
+  for (int c = threadIdx.x; c < C; c += 256) a += (double)v[c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// out[c] = column sums of the partial rows; reduce_all: out[0] = their sum over channels, through the scratch row
+// partial[nblk][*] (the caller's partial buffer holds vmtl_reduce_rows(M) + 1 rows)
+static void colsum_finish(float* partial, int nblk, int C, int Cs, int reduce_all, float* out, hipStream_t st) {
+  float* per_channel = reduce_all ? partial + (size_t)nblk * Cs : out;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, Cs, per_channel);
+  if (reduce_all) hipLaunchKernelGGL(sum_channels_kernel, dim3(1), dim3(256), 0, st, per_channel, C, out);
 }
 
 // cross-stitch backward in one sweep (reference models/cross_stitch_model.py:21-37): dx = w * dy and the partial
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(RED_THREADS) void stitch_bwd_kernel(const float* __
 }
 
 // dx (nullable) = w[c * wstride] * dy;  dw[c] = sum_m x*dy  (reduce_all: one scalar, the layer-wise stitch weight).
-// partial: vmtl_reduce_rows(M) * Cs floats.
+// partial: (vmtl_reduce_rows(M) + 1) * Cs floats (the last row is scratch for reduce_all).
 extern "C" int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, float* dx, float* partial, float* dw,
                                int M, int C, int Cs, int wstride, int reduce_all, void* stream) {
   VMTL_ENTER();
@@ -697,8 +713,7 @@ extern "C" int vmtl_stitch_bwd(const float* x, const float* dy, const float* w, 
   hipStream_t st = (hipStream_t)stream;
   const int nblk = red_blocks(M);
   hipLaunchKernelGGL(stitch_bwd_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, x, dy, w, dx, M, C, Cs, wstride, partial);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(reduce_all ? 1 : C), dim3(256), 0, st, partial, nblk, C, Cs,
-                     reduce_all, dw);
+  colsum_finish(partial, nblk, C, Cs, reduce_all, dw, st);
   return vmtl_check_launch();
 }
 
@@ -709,7 +724,6 @@ extern "C" int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs,
   hipStream_t st = (hipStream_t)stream;
   const int nblk = red_blocks(M);
   hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(RED_THREADS), 0, st, a, b, M, Cs, mode, partial);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(reduce_all ? 1 : C), dim3(256), 0, st, partial, nblk, C, Cs,
-                     reduce_all, out);
+  colsum_finish(partial, nblk, C, Cs, reduce_all, out, st);
   return vmtl_check_launch();
 }

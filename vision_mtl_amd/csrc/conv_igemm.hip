@@ -26,6 +26,9 @@
 // 16 bytes) and slot s of row r lives at slot s ^ (r & 7): with that swizzle every 16-lane group of the
 // fragment ds_read_b128 (and every 8-lane group of the staging ds_write_b128) touches 16 (8) distinct
 // slots - conflict-free, where the padded [row][BK+4] layout measured 36 % conflict cycles.
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 #define BK 32
@@ -757,7 +760,12 @@ static_assert(wg_ld(16) == 16 && wg_ld(20) == 80 && wg_ld(144) == 144 && wg_ld(1
 // co rows per workgroup = TM * 16 (+ NTR "tail" rows: the 33rd / 17-20th / 65-68th output channel is not
 // given an MFMA tile of its own - each lane multiplies its X fragment with the tail dY values on the VALU,
 // the same trick as the tail columns of conv_igemm_kernel); waves are laid out 1 x 4 along kk
-template <int TM, int NTR = 0, int PM = 1>
+// PD = pixel chunks in flight in registers ahead of the one being multiplied.  A chunk of a NARROW tile is 16-64 MFMAs
+// per wave (0.5-2 k cycles) against ~4-5 k cycles of loaded memory latency: with one chunk in flight (round 2) the 32- and
+// 36-row tiles ran at 36 % of the matrix pipe (wgrad M = 1 M, N = 33: 51 TF; MTAN N = 32: 56 TF), latency-bound; the
+// tall tiles (>= 80 rows: 160+ MFMAs per chunk) cover it with PD = 1 and have no registers to spare (the 68-row tile
+// would drop from 3 to 2 waves per SIMD at PD = 2: 196 VGPRs).
+template <int TM, int NTR = 0, int PM = 1, int PD = (TM <= 2 ? 3 : (TM <= 4 && NTR == 0) ? 2 : 1)>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int TN = 2;
   constexpr int BMM = TM * 16;    // rows covered by MFMA tiles
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     xwo[i] = rem - xho[i] * p.Wo;
   }
 
-  f32x4 ry[YIT], rx[XP];
+  f32x4 ry[PD][YIT], rx[PD][XP];
   // buffer loads: 32-bit offsets, out-of-range (slice end, image border, tile edge) reads return zeros
   const __amdgpu_buffer_rsrc_t rs_dy =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)((unsigned)p.M * p.ldy * 4u), 0x00020000);
@@ -828,14 +836,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
   };
-  auto load_tile = [&](int pp) {
+  // slot: compile-time index after unrolling (register arrays must not be indexed at run time)
+  auto load_tile = [&](int pp, f32x4* ry_s, f32x4* rx_s) {
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
       const int idx = tid + it * 256;
       const int row = idx / YQ, q = idx - row * YQ;
       const int m = pp + row, co = co0 + q * 4;
       const bool ok = idx < BP * YQ && m < p_end && co < p.ldy;
-      ry[it] = bload(rs_dy, ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u : OOB);
+      ry_s[it] = bload(rs_dy, ok ? ((unsigned)m * (unsigned)p.ldy + (unsigned)co) * 4u : OOB);
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       } else {
         v = bload(rs_x, ok ? off : OOB);
       }
-      rx[i] = v;
+      rx_s[i] = v;
       // advance this row by BP pixels
       xwo[i] += BP;
       while (xwo[i] >= p.Wo) {
@@ -862,17 +871,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const f32x4* ry_s, const f32x4* rx_s) {
     float* ys = Ys + buf * BP * LDY;
     float* xs = Xs + buf * BP * LDX;
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
       const int idx = tid + it * 256;
       const int row = idx / YQ, q = idx - row * YQ;
-      if (idx < BP * YQ) *reinterpret_cast<f32x4*>(ys + row * LDY + q * 4) = ry[it];
+      if (idx < BP * YQ) *reinterpret_cast<f32x4*>(ys + row * LDY + q * 4) = ry_s[it];
     }
 #pragma unroll
-    for (int i = 0; i < XP; ++i) *reinterpret_cast<f32x4*>(xs + (xr + XROWS * i) * LDX + xq * 4) = rx[i];
+    for (int i = 0; i < XP; ++i) *reinterpret_cast<f32x4*>(xs + (xr + XROWS * i) * LDX + xq * 4) = rx_s[i];
   };
 
   f32x4 acc[TM][TN];
@@ -887,17 +896,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     for (int j = 0; j < TN; ++j) tacc[t][j] = 0.f;
 
   const int ntr = NTR > 0 ? max(0, min(NTR, p.Nw - (co0 + BMM))) : 0;
-  if (p_begin < p_end) {
-    load_tile(p_begin);
-    store_tile(0);
-  }
+  // chunks pp = p_begin + it * BP; chunk it lives in register slot it % PD until it is stored to LDS buffer it & 1
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+    if (p_begin + d * BP < p_end) load_tile(p_begin + d * BP, ry[d], rx[d]);
+  if (p_begin < p_end) store_tile(0, ry[0], rx[0]);
   __syncthreads();
   int cur = 0;
-  for (int pp = p_begin; pp < p_end; pp += BP) {
-    const bool more = pp + BP < p_end;
-    if (more) load_tile(pp + BP);
-    const float* ys = Ys + cur * BP * LDY + lq * LDY + l15;
-    const float* xs = Xs + cur * BP * LDX + lq * LDX + wn * TN * 16 + l15;
+  auto compute = [&](int cb) {
+    const float* ys = Ys + cb * BP * LDY + lq * LDY + l15;
+    const float* xs = Xs + cb * BP * LDX + lq * LDX + wn * TN * 16 + l15;
 #pragma unroll
     for (int s = 0; s < BP / 4; ++s) {  // 4 pixels per MFMA: lane quarter q supplies pixel 4s+q
       float fa[TM], fb[TN];
@@ -911,7 +919,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
       if (NTR > 0) {  // dY[pixel 4s+lq][BMM .. BMM+3]: one 16-byte LDS read, broadcast within the quarter
-        const f32x4 ty = *reinterpret_cast<const f32x4*>(Ys + cur * BP * LDY + (4 * s + lq) * LDY + BMM);
+        const f32x4 ty = *reinterpret_cast<const f32x4*>(Ys + cb * BP * LDY + (4 * s + lq) * LDY + BMM);
 #pragma unroll
         for (int t = 0; t < NTR; ++t) {
           if (t >= ntr) break;  // dY columns past Nw are zero pad lanes
@@ -920,9 +928,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         }
       }
     }
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+  };
+  for (int base = p_begin; base < p_end; base += PD * BP) {
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {  // unrolled: slot indices k and (k + 1) % PD are compile-time constants
+      const int pp = base + k * BP;
+      if (pp < p_end) {  // uniform over the workgroup
+        // slot k held chunk pp: it went to LDS one step ago (or in the prologue); refill it PD chunks ahead
+        if (pp + PD * BP < p_end) load_tile(pp + PD * BP, ry[k], rx[k]);
+        compute(cur);
+        if (pp + BP < p_end) store_tile(cur ^ 1, ry[(k + 1) % PD], rx[(k + 1) % PD]);
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
   }
 
   float* slab = p.slabs + (size_t)zsl * p.Nw * p.Ktot;
@@ -1346,11 +1365,39 @@ static int wgrad_rows(int Nw) {
   return best;
 }
 
-// number of pixel slices (= slabs the caller must provide: splits * Nw * Ktot floats)
+// LDS bytes of one weight-gradient workgroup under the stride rule its tile height gets (wg_pm)
+static int wgrad_lds_bytes(int rows) {
+  auto lds = [&](int pm) { return 2 * BP * (wg_ld(rows, pm) + wg_ld(WG_BNK, pm)) * 4; };
+  const int base = 160 * 1024 / lds(0);
+  if (160 * 1024 / lds(1) >= base) return lds(1);
+  if (160 * 1024 / lds(2) >= base) return lds(2);
+  return lds(0);
+}
+
+static int wgrad_splits_uncached(int M, int Nw, int Ktot);
+
+// number of pixel slices (= slabs the caller must provide: splits * Nw * Ktot floats); memoised: the search below walks
+// up to a few thousand candidates, and this is called twice per weight-gradient launch on the (eager) launch path
 extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   if (M <= 0 || Nw <= 0 || Ktot <= 0) return 0;
+  static std::mutex mu;
+  static std::unordered_map<unsigned long long, int> memo;
+  static int memo_epoch = 0;
+  const unsigned long long key = ((unsigned long long)M << 32) ^ ((unsigned long long)Nw << 20) ^ (unsigned long long)Ktot;
+  std::lock_guard<std::mutex> lk(mu);
+  if (memo_epoch != vmtl_env_epoch) {  // the tuning overrides may have changed
+    memo.clear();
+    memo_epoch = vmtl_env_epoch;
+  }
+  auto it = memo.find(key);
+  if (it != memo.end()) return it->second;
+  const int v = wgrad_splits_uncached(M, Nw, Ktot);
+  memo.emplace(key, v);
+  return v;
+}
+
+static int wgrad_splits_uncached(int M, int Nw, int Ktot) {
   const long long tiles = (long long)cdiv(Ktot, WG_BNK) * cdiv(Nw, wgrad_rows(Nw));
-  long long splits = cdivll(1536, tiles);
   // Pixels per slice: at least 16 K-steps (512) - except for SMALL problems (<= 16384 pixels: the deep encoder layers,
   // whose tile grid is a few dozen workgroups): there 4 K-steps per slice, parallelism over the chip beats the longer
   // slab sum (the 1x1 weight gradients at M = 1024 / 4096 ran 45-60 us on 28-72 workgroups; basic bs32 14.4 -> 14.0
@@ -1359,14 +1406,40 @@ extern "C" int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot) {
   const int min_steps = env_int(e_steps) < 1 ? 1 : env_int(e_steps), small_m = env_int(e_small);
   const long long max_by_rows = cdiv(M, (M <= small_m ? min_steps : 16) * BP);
   const long long max_by_mem = (32ll << 20) / ((long long)Nw * Ktot);  // slabs <= 128 MB
-  if (splits > max_by_rows) splits = max_by_rows;
-  if (splits > max_by_mem) splits = max_by_mem;
-  if (splits < 1) splits = 1;
+  long long smax = max_by_rows < max_by_mem ? max_by_rows : max_by_mem;
+  if (smax < 1) smax = 1;
   if (const long long v = env_int(e_splits)) {
-    if (v >= 1 && v <= max_by_rows) splits = v;
+    if (v >= 1 && v <= max_by_rows) {
+      const int chunk = cdiv(cdiv(M, (int)v), BP) * BP;
+      return cdiv(M, chunk);
+    }
   }
-  const int chunk = cdiv(cdiv(M, (int)splits), BP) * BP;
-  return cdiv(M, chunk);
+  // Wave quantisation: the grid is tiles x slices workgroups on 256 CUs x (workgroups per CU) slots and runs in whole
+  // ROUNDS - 1280 workgroups on 512 slots take three rounds of 512-pixel slices where 980 workgroups of 672 pixels take
+  // two (decoder block 2: 228 us at 2.5 rounds).  Pick the slice count that minimises
+  //   rounds * (pixels per slice + fixed cost of a workgroup) * time per pixel  +  slices * slab bytes / unpack rate
+  // (round 2 took 1536 / tiles slices whatever the remainder).
+  const int rows = wgrad_rows(Nw);
+  int occ = 160 * 1024 / wgrad_lds_bytes(rows);
+  if (occ > 4) occ = 4;
+  if (rows >= 144 && occ > 2) occ = 2;
+  const long long slots = 256ll * occ;
+  const double t_pix = (rows / 16.0) * occ * 0.0095;             // us per pixel of a round (MFMA-paced, measured ~0.7 eff)
+  const double t_slab = (double)Nw * Ktot * 4.0 / 3.0e6;          // us per slab in the slab sum (vmtl_unpack_weights)
+  long long best = 1;
+  double best_cost = -1.0;
+  for (long long sp = 1; sp <= smax; ++sp) {
+    const int chunk = cdiv(cdiv(M, (int)sp), BP) * BP;
+    const long long nsl = cdiv(M, chunk);
+    if (nsl != sp && sp != 1) continue;  // slice counts that collapse onto another one
+    const long long rounds = cdivll(tiles * nsl, slots);
+    const double cost = rounds * (chunk + 64.0) * t_pix + nsl * t_slab;
+    if (best_cost < 0.0 || cost < best_cost) {
+      best = nsl;
+      best_cost = cost;
+    }
+  }
+  return (int)best;
 }
 
 template <int TM, int NTR, int PM>

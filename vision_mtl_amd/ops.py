@@ -182,6 +182,7 @@ class _SideBranch:
         self.join_at_end_of_backward()
         self.pending[s] = True
         with torch.cuda.stream(s):
+
             self.in_branch = True
             try:
                 yield
@@ -418,7 +419,7 @@ def _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Nw, KH, KW, stride, pad, flop, xflop
 
 
 def _colsum(a, b, M, C, Cs, mode=0, reduce_all=0, out=None):
-    partial = _empty((_reduce_rows(M), Cs), a)
+    partial = _empty((_reduce_rows(M) + 1, Cs), a)  # + 1: scratch row of the reduce_all form
     if out is None:
         out = _empty((1 if reduce_all else C,), a)
     _k("vmtl_colsum", a=a, b=b, M=M, C=C, Cs=Cs, mode=mode, reduce_all=reduce_all, partial=partial, out=out)
@@ -429,18 +430,24 @@ def _bias_grad(bias, slot, dy, M, Cout, ldy, zero, fork):
     """dL/dbias of a conv (column sums of dy), into its arena slot when there is one (returns None then).
     zero: the conv feeds a TRAIN-mode BatchNorm - the batch mean absorbs the bias, its gradient is exactly 0.  This
     function is the slot's only writer, so the zero is written ONCE (first backward pass) and remembered
-    (FlatArena._zero_bias); later steps launch nothing - MTAN's 56 attention-conv biases cost 56 memset launches per step
-    before.  Column sums written later (an eval-mode BatchNorm step) or FlatArena.slots_clobbered() forget it."""
+    (FlatArena._zero_bias): eager steps launch nothing afterwards (MTAN: 56 memset launches per step before).  Column
+    sums written later (an eval-mode BatchNorm step) or FlatArena.slots_clobbered() forget it.
+    Inside a hipGraph CAPTURE the (4..2048-byte) memset is still recorded, on the side branch: measured on MI355X /
+    ROCm 7.0 runtime (MTAN 256x256 bs 16, round 3), the replayed graph runs its side branch CONCURRENTLY with the main
+    chain only when these memset nodes are part of it - 52.3 ms/step with them, 55.7-57.8 without (side branch started
+    after the last main-chain kernel: two-stream timeline of VMTL_STAMPS=1); one memset per step, one per branch entry
+    and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 did not reproduce it.  They are off the critical path (side branch, ~2 us)."""
     arena = getattr(bias, "_vmtl_arena", None) if slot is not None else None
     if zero:
         if slot is None:
             db = _empty((Cout,), dy)
             _k("vmtl_fill_zero", p=db, n=Cout)
             return db
-        if arena is None or id(bias) not in arena._zero_bias:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if arena is None or id(bias) not in arena._zero_bias or (capturing and side.enabled and not side.task_mode):
             with side.branch(True, M, fork, dy):
                 _k("vmtl_fill_zero", p=slot, n=Cout)
-            if arena is not None and not torch.cuda.is_current_stream_capturing():
+            if arena is not None and not capturing:
                 arena._zero_bias.add(id(bias))
         return None
     with side.branch(slot is not None, M, fork, dy):
@@ -1623,7 +1630,7 @@ class _Stitch(torch.autograd.Function):
                 out = dw.view(-1)[off:off + n]
             dx = _empty(x.shape, x) if ctx.needs_input_grad[0] else None
             # one sweep: dx = w * dy and the column sums of x * dy
-            _k("vmtl_stitch_bwd", x=x, dy=dy, w=wv, dx=dx, partial=_empty((_reduce_rows(M), Cs), x), dw=out, M=M, C=C, Cs=Cs,
+            _k("vmtl_stitch_bwd", x=x, dy=dy, w=wv, dx=dx, partial=_empty((_reduce_rows(M) + 1, Cs), x), dw=out, M=M, C=C, Cs=Cs,
                wstride=ws, reduce_all=0 if channel_wise else 1)
         elif ctx.needs_input_grad[0]:
             dx = _empty(x.shape, x)
