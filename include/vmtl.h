@@ -64,8 +64,11 @@ int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per 
  * fragments straight from global memory, K split over the waves of a workgroup when the tile grid is small
  * (csrc/conv_pw.hip).  stats (optional): [vmtl_conv1x1_stats_rows][2][ldy] per-row-block (mean, M2) of y,
  * vmtl_conv1x1_stats_block rows each. */
-int vmtl_conv1x1_stats_block(int M, int ldy, int Ks);
-int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks);
+/* variant 0: forward-type launches (vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad; large problems run on the
+ * persistent large-M kernel, whose row block differs); 1: launches with a BatchNorm-backward epilogue or a residual
+ * operand (vmtl_conv1x1_bnbwd*, vmtl_conv1x1_bn_res_fwd) */
+int vmtl_conv1x1_stats_block(int M, int ldy, int Ks, int variant);
+int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks, int variant);
 int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,
                      int Nw, int Cout, void* stream);
 /* conv1x1(cat[x, x2]) without the concat (mtan_model.py:57-59,139-141): x [M][K1] (K1 % 4 == 0), x2 [M][K2s], packed

@@ -276,6 +276,232 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   (void)cnt;
 }
 
+
+// ---------------------------------------------------------------------------------------------- large-M kernel
+// The same GEMM for LARGE row counts (MTAN's attention 1x1 convs at 128^2 / 256^2 pixels, bs 16: M = 262144 / 1048576,
+// K = 64..384, N = 32..192; reference models/mtan_model.py:31,39,57-66,105,113,139-148).  There the kernel above runs at
+// 1.7-2.5 TB/s and 60-70 TF - neither roofline (profiles/r02_mtan_*): fragments straight from global memory read A in
+// 64-byte row segments, twice for N = 128 (two 64-column tiles), and every workgroup re-fetches B.  Here
+//   * PERSISTENT workgroups (one per CU) keep the whole weight matrix B [BN][K] in LDS, loaded once;
+//   * A is streamed ONE ROW TILE [BM][K] AT A TIME: every thread fetches its 128-byte-coalesced share of tile t+1 into
+//     registers BEFORE the K loop of tile t and stores it to LDS after tile t's epilogue - one full tile (32-128 KB per
+//     CU) is in flight under the MFMAs, and the K loop itself has NO barrier and no global traffic (all of K is in LDS);
+//   * full-width tiles: N <= 128 is one column tile, A is read exactly once;
+//   * barriers are LDS-only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also wait for the prefetch;
+//   * the pre-activation prologue act(pa*x + pc) runs when a tile is STAGED (once per element, not per fragment use) and
+//     the activated matrix goes back to HBM as the coalesced rows it was loaded in;
+//   * epilogue as above (bias, pad-channel zeros, per-tile BatchNorm (mean, M2), two-destination split store).
+// LDS images are [K chunk of 32][row][32 floats] with the 16-byte slot XOR-swizzled by (row & 7): the layout of
+// conv_igemm.hip's staging tiles (0 bank-conflict cycles measured there), for A and B alike.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wave tile (TM*16) x (TN*16), WM x WN waves; KC = K chunks of 32 the instantiation can hold (Ks <= 32 * KC)
+template <int TM, int TN, int WM, int WN, int KC, bool SRC2, bool PRO>
+__global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int RA = BM / 32, RB = (BN + 31) / 32;  // staging rows per thread and chunk
+  constexpr int OS = BN + 4;                         // output tile row stride (floats)
+  constexpr int A_FLOATS = KC * BM * 32, O_FLOATS = BM * OS;
+  constexpr int AO_FLOATS = A_FLOATS > O_FLOATS ? A_FLOATS : O_FLOATS;  // the output tile aliases the A image
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                 // [KC][BN][32]
+  float* As = smem + KC * BN * 32;  // [KC][BM][32]  | output tile [BM][OS]
+  f32x4* red = reinterpret_cast<f32x4*>(As + AO_FLOATS);  // [2][256]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int wm = wv / WN, wn = wv % WN;
+  const int tile_n = blockIdx.y, n0 = tile_n * BN;
+  const int nkc = (p.Ks + 31) >> 5;   // K chunks in use (<= KC)
+  const int nkg = (p.Ks + 15) >> 4;   // 16-wide k-groups in use
+  const int r0 = tid >> 3, kq = tid & 7;
+  const int ks = (kq ^ (r0 & 7)) * 4;  // swizzled slot of this thread's k-quad ((r0 + 32 i) & 7 == r0 & 7)
+  const int lda = SRC2 ? p.K1 : p.Ks;
+
+  // ---- B: the whole [BN][Ks] weight tile, once ----
+#pragma unroll
+  for (int c = 0; c < KC; ++c)
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = r0 + 32 * i, n = n0 + row, k = 32 * c + 4 * kq;
+      if (BN % 32 == 0 || row < BN) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < nkc && n < p.Nw && k < p.Ks) v = *reinterpret_cast<const f32x4*>(p.wp + (size_t)n * p.Ks + k);
+        *reinterpret_cast<f32x4*>(Bs + (c * BN + row) * 32 + ks) = v;
+      }
+    }
+  // prologue coefficients of this thread's k-quads (fixed per thread: one quad per chunk)
+  f32x4 cpa[PRO ? KC : 1], cpc[PRO ? KC : 1];
+  if (PRO) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = 32 * c + 4 * kq;
+      const bool ok = c < nkc && k < p.Ks;
+      cpa[c] = ok ? *reinterpret_cast<const f32x4*>(p.pa + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      cpc[c] = ok ? *reinterpret_cast<const f32x4*>(p.pc + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ---- A tile prefetch: pre[c][i] = x[m0 + r0 + 32 i][32 c + 4 kq .. +3] ----
+  f32x4 pre[KC][RA];
+  auto fetch = [&](int tile_m) {
+    const int m0 = tile_m * BM;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = 32 * c + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < nkc && m < p.M && k < p.Ks) {
+          const float* src = (SRC2 && k >= p.K1) ? p.x2 + (size_t)m * (p.Ks - p.K1) + (k - p.K1) : p.x + (size_t)m * lda + k;
+          v = *reinterpret_cast<const f32x4*>(src);
+        }
+        pre[c][i] = v;
+      }
+    }
+  };
+  auto stage = [&](int tile_m) {  // registers -> LDS (+ prologue, + activated copy back to HBM)
+    const int m0 = tile_m * BM;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c < nkc) {
+        const int k = 32 * c + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          f32x4 v = pre[c][i];
+          if (PRO) {
+            v = v * cpa[c] + cpc[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act_in);
+            const int m = m0 + r0 + 32 * i;
+            if (p.a_out != nullptr && tile_n == 0 && m < p.M && k < p.Ks)
+              *reinterpret_cast<f32x4*>(p.a_out + (size_t)m * p.Ks + k) = v;
+            if (m >= p.M) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // rows past M: act(pc) need not be 0
+          }
+          *reinterpret_cast<f32x4*>(As + (c * BM + r0 + 32 * i) * 32 + ks) = v;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+  // epilogue geometry: thread <-> (row, column quad)
+  constexpr int Q = BN / 4, RPP = 256 / Q, PASSES = (BM + RPP - 1) / RPP;
+  const int q = tid % Q, er0 = tid / Q;
+  const int n4 = n0 + 4 * q;
+  const bool ethread = er0 < RPP;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n4 + e < p.Nw) bias4[e] = p.bias[n4 + e];
+  }
+
+  int tile_m = blockIdx.x;
+  if (tile_m < p.tiles_m) fetch(tile_m);
+  bool first = true;
+  for (; tile_m < p.tiles_m; tile_m += nprog) {
+    // tile_m's rows are in `pre` (in flight or landed): LDS image is free (first tile: B stores above need the barrier too)
+    stage(tile_m);
+    lds_barrier();
+    first = false;
+    const int next = tile_m + nprog;
+    if (next < p.tiles_m) fetch(next);  // stays in flight under the K loop, the epilogue and its stores
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- K loop: no barrier, no global traffic ----
+    const float* a = As + ((wm * TM * 16 + l15) * 32);
+    const float* b = Bs + ((wn * TN * 16 + l15) * 32);
+    for (int g = 0; g < nkg; ++g) {
+      const int c = g >> 1;
+      const int so = ((((g & 1) << 2) + lq) ^ (l15 & 7)) * 4;
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + (c * BM + i * 16) * 32 + so);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + (c * BN + j * 16) * 32 + so);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    lds_barrier();  // every wave is done reading the A image: it becomes the output tile
+    float* tile = As;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          tile[((wm * TM + i) * 16 + 4 * lq + r) * OS + (wn * TN + j) * 16 + l15] = acc[i][j][r];
+    lds_barrier();
+    // ---- epilogue: bias, pad zeros, coalesced float4 stores, per-tile (mean, M2) ----
+    const int m0 = tile_m * BM;
+    f32x4 val[PASSES];
+    if (ethread) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int r = er0 + ps * RPP;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < BM && m0 + r < p.M) {
+          v = *reinterpret_cast<const f32x4*>(tile + r * OS + 4 * q) + bias4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n4 + e >= p.Cout) v[e] = 0.f;
+          const int m = m0 + r;
+          if (n4 < p.ldy) {
+            if (p.y2 == nullptr) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n4) = v;
+            else if (n4 < p.N1) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.N1 + n4) = v;
+            else *reinterpret_cast<f32x4*>(p.y2 + (size_t)m * (p.ldy - p.N1) + (n4 - p.N1)) = v;
+          }
+        }
+        val[ps] = v;
+      }
+    }
+    if (p.stats != nullptr) {
+      // shifted sums around the column's value in the tile's first row (accurate when |mean| >> std)
+      const int nvalid = min(BM, p.M - m0);
+      f32x4 pv = {0.f, 0.f, 0.f, 0.f}, d1 = pv, d2 = pv;
+      if (ethread) {
+        pv = *reinterpret_cast<const f32x4*>(tile + 4 * q) + bias4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n4 + e >= p.Cout) pv[e] = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+          if (er0 + ps * RPP < BM && m0 + er0 + ps * RPP < p.M) {
+            const f32x4 d = val[ps] - pv;
+            d1 += d;
+            d2 += d * d;
+          }
+      }
+      red[tid] = d1;
+      red[256 + tid] = d2;
+      lds_barrier();
+      if (tid < Q && n4 < p.ldy) {  // er0 == 0: q == tid
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sc = sa;
+#pragma unroll
+        for (int k = 0; k < RPP; ++k) {
+          sa += red[tid + Q * k];
+          sc += red[256 + tid + Q * k];
+        }
+        const float inv = 1.f / (float)nvalid;
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = pv + sa * inv;
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = sc - sa * sa * inv;
+      }
+    }
+    lds_barrier();  // the output tile has been read: the region takes the next A image
+  }
+  (void)first;
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 // (TN, KW) for a problem: 64-wide tiles unless N <= 32; split K over the 4 waves when the 128-row tiling leaves the
 // chip under-filled and there is K to split
@@ -289,13 +515,103 @@ static void pw_pick(int M, int ldy, int Ks, int* tn, int* kw) {
   if (v == 1 || v == 4) *kw = v;
 }
 
-extern "C" int vmtl_conv1x1_stats_block(int M, int ldy, int Ks) {
+// ---- large-M path: configuration id for a problem, or -1 (see pw_big_kernel) ----
+//  id  wave tile x waves      BM x BN    KC (K <= 32 KC)
+//   0  <2,4> x 2x2            64 x 128   2, 4, 6
+//   1  <2,2> x 2x2            64 x 64    4, 8
+//   2  <4,2> x 4x1           256 x 32    4
+//   3  <2,3> x 2x2            64 x 96    4
+struct BigCfg { int id, bm, bn, kc; };
+static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
+  static EnvInt e_on{"VMTL_PW_BIG", 1};  // tuning aid: 0 = every 1x1 conv on pw_gemm_kernel
+  if (!env_int(e_on)) return false;
+  // large problems only: below, the fragment-from-global kernel wins on launch latency (and the encoder chains of
+  // basic / csnet - K = 16..960 at M <= 262144 - stay on it)
+  if (M < 65536 || Ks < 32 || Ks > 256 || ldy < 32 || (long long)M * ldy < (1ll << 23)) return false;
+  const int kc = Ks <= 64 ? 2 : Ks <= 128 ? 4 : Ks <= 192 ? 6 : 8;
+  BigCfg c;
+  if (ldy <= 32) {
+    if (Ks > 128) return false;
+    c = {2, 256, 32, 4};
+  } else if (ldy <= 64) {
+    c = {1, 64, 64, Ks <= 128 ? 4 : 8};
+  } else if (Ks > 192) {
+    c = {1, 64, 64, 8};  // B [128][256] does not fit next to A: 64-column tiles (A re-read from L2)
+  } else if (ldy % 96 == 0 && ldy % 128 != 0 && Ks <= 128) {
+    c = {3, 64, 96, 4};
+  } else {
+    c = {0, 64, 128, kc};
+  }
+  if (c.id == 1 && c.kc < 4) c.kc = 4;
+  *out = c;
+  return true;
+}
+
+// variant 0: forward-type launches (vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad); 1: launches that always run on
+// pw_gemm_kernel (BatchNorm-backward epilogue, residual operand)
+extern "C" int vmtl_conv1x1_stats_block(int M, int ldy, int Ks, int variant) {
+  BigCfg c;
+  if (variant == 0 && pw_big_cfg(M, ldy, Ks, &c)) return c.bm;
   int tn, kw;
   pw_pick(M, ldy, Ks, &tn, &kw);
   return (4 / kw) * 32;
 }
 
-extern "C" int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks) { return cdiv(M, vmtl_conv1x1_stats_block(M, ldy, Ks)); }
+extern "C" int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks, int variant) {
+  return cdiv(M, vmtl_conv1x1_stats_block(M, ldy, Ks, variant));
+}
+
+static int pw_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ? prop.multiProcessorCount
+            : 256;
+  }
+  return n;
+}
+
+template <int TM, int TN, int WM, int WN, int KC>
+static int launch_pw_big(PwP& p, hipStream_t st) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int A_FLOATS = KC * BM * 32, O_FLOATS = BM * (BN + 4);
+  constexpr size_t lds = ((size_t)KC * BN * 32 + (A_FLOATS > O_FLOATS ? A_FLOATS : O_FLOATS)) * 4 + 2 * 256 * 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.ldy, BN);
+  int nprog = pw_num_cus() / p.tiles_n;
+  if (nprog < 1) nprog = 1;
+  if (nprog > p.tiles_m) nprog = p.tiles_m;
+  const dim3 grid(nprog, p.tiles_n);
+#define VMTL_PW_BIG_LAUNCH(SRC2, PRO)                                                                                   \
+  {                                                                                                                     \
+    static bool attr_set = false;                                                                                       \
+    if (!attr_set) {                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO>),           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      attr_set = true;                                                                                                  \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO>), grid, dim3(256), lds, st, p, nprog);             \
+  }
+  if (p.x2 != nullptr) VMTL_PW_BIG_LAUNCH(true, false)
+  else if (p.pa != nullptr) VMTL_PW_BIG_LAUNCH(false, true)
+  else VMTL_PW_BIG_LAUNCH(false, false)
+#undef VMTL_PW_BIG_LAUNCH
+  return vmtl_check_launch();
+}
+
+static int pw_big_dispatch(PwP& p, const BigCfg& c, hipStream_t st) {
+  switch (c.id) {
+    case 0:
+      return c.kc == 2 ? launch_pw_big<2, 4, 2, 2, 2>(p, st) : c.kc == 4 ? launch_pw_big<2, 4, 2, 2, 4>(p, st)
+                                                                        : launch_pw_big<2, 4, 2, 2, 6>(p, st);
+    case 1: return c.kc == 4 ? launch_pw_big<2, 2, 2, 2, 4>(p, st) : launch_pw_big<2, 2, 2, 2, 8>(p, st);
+    case 2: return launch_pw_big<4, 2, 4, 1, 4>(p, st);
+    default: return launch_pw_big<2, 3, 2, 2, 4>(p, st);
+  }
+}
 
 template <int TN, int KW>
 static int launch_pw(PwP& p, hipStream_t st) {
@@ -316,6 +632,8 @@ static void pw_plain(PwP& p) {  // no prologue, ordinary epilogue
 }
 
 static int pw_dispatch(PwP& p, hipStream_t st) {
+  BigCfg c;
+  if (p.ez_x == nullptr && p.res == nullptr && pw_big_cfg(p.M, p.ldy, p.Ks, &c)) return pw_big_dispatch(p, c, st);
   int tn, kw;
   pw_pick(p.M, p.ldy, p.Ks, &tn, &kw);
   if (tn == 2) return kw == 4 ? launch_pw<2, 4>(p, st) : launch_pw<2, 1>(p, st);

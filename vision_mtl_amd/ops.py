@@ -480,7 +480,7 @@ def conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad):
     """(rows, pixels per row) of the BatchNorm partial rows a conv launch of this shape emits from its epilogue."""
     if _is_pw(B, Ho, Wo, KH, KW, stride, pad):
         M = B * Ho * Wo
-        return lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs), lib().raw("vmtl_conv1x1_stats_block")(M, ldy, Cs)
+        return lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs, 0), lib().raw("vmtl_conv1x1_stats_block")(M, ldy, Cs, 0)
     return lib().raw("vmtl_conv2d_stats_rows")(B, Ho, Wo, ldy), lib().raw("vmtl_conv2d_stats_block")(B, Ho, Wo, ldy)
 
 
@@ -601,7 +601,7 @@ class _BNActPw(torch.autograd.Function):
         a, y = _empty(x.shape, x), _empty((B, H, W, ldy), x)
         ostats = None
         if want_stats:
-            ostats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs), 2, ldy), x)
+            ostats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs, 0 if res is None else 1), 2, ldy), x)
         if res is None:
             _k("vmtl_conv1x1_bn_fwd", _flop=2.0 * M * Cout * Cin, x=x, coef_a=ca, coef_c=cc, act_in=act, a_out=a, wp=wp,
                bias=bias, y=y, stats=ostats, M=M, Ks=Cs, ldy=ldy, Nw=Cout, Cout=Cout)
@@ -639,7 +639,7 @@ class _BNActPw(torch.autograd.Function):
         dgamma = _empty((C,), x) if sg is None else sg
         dbeta = _empty((C,), x) if sb is None else sb
         dz = _empty(x.shape, x)
-        rows = lib().raw("vmtl_conv1x1_stats_rows")(M, Cs, ldy)
+        rows = lib().raw("vmtl_conv1x1_stats_rows")(M, Cs, ldy, 1)
         part = _empty((rows, 2, Cs), x)
         if d_a is None:
             _k("vmtl_conv1x1_bnbwd", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, dz=dz, stats=part, ez_x=x, ez_mean=mean,
@@ -693,7 +693,8 @@ def bn_act_conv1x1(x, stats, rpb, bn, C, act, weight, bias=None, want_stats=True
     y, ostats = out[0], out[1]
     orpb = 0
     if ostats is not None:
-        orpb = lib().raw("vmtl_conv1x1_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3], x.shape[3])
+        orpb = lib().raw("vmtl_conv1x1_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3], x.shape[3],
+                                                     0 if res is None else 1)
     return (y, ostats, orpb, out[2]) if return_act else (y, ostats, orpb)
 
 
@@ -716,7 +717,7 @@ class _Conv1x1Cat(torch.autograd.Function):
         y = _empty((B, H, W, ldy), xa)
         stats = None
         if want_stats:
-            stats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Ks), 2, ldy), xa)
+            stats = _empty((lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Ks, 0), 2, ldy), xa)
         _k("vmtl_conv1x1_cat_fwd", _flop=2.0 * M * Cout * Cin, x=xa, K1=Ca, x2=xb, K2s=Cbs, wp=wp, bias=bias, y=y, stats=stats,
            M=M, ldy=ldy, Nw=Cout, Cout=Cout)
         ctx.save_for_backward(xa, xb, weight)
@@ -773,7 +774,7 @@ def conv1x1_cat(xa, xb, Cb, weight, bias=None, want_stats=False, zero_bias_grad=
     y, stats = _Conv1x1Cat.apply(xa, xb, weight, bias, Cb, want_stats, zero_bias_grad)
     if stats is not None:
         stats._vmtl_rpb = lib().raw("vmtl_conv1x1_stats_block")(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3],
-                                                                xa.shape[3] + xb.shape[3])
+                                                                xa.shape[3] + xb.shape[3], 0)
     return y, stats
 
 
