@@ -181,8 +181,21 @@ int vmtl_dwconv_bwd_weight(const float* x, const float* dy, float* partial, floa
 /* torch parameter layout <-> packed GEMM operand (formula in csrc/pack.hip). */
 int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
                       long long sr0, long long st, long long sc, int flip, void* stream);
-/* batched form: descs = device array of n records {src*, dst*, i64 sr1, sr0, st, sc, start; i32 R1, R0, T, C,
- * Cs, flip} (vmtl_pack_desc_bytes() bytes each), start = first flat work index; total = sum R1*R0*T*Cs. */
+/* the same with a per-input-channel factor folded into the operand: the cross-stitch scale of the tensor the conv reads
+ * (models/cross_stitch_model.py:32-37 followed by the next conv of the CSNet walk :108-142) - conv(W, s*x) = conv(W*s, x).
+ * smode 1: packed column channel = input channel (forward packing); 2: packed row (data-gradient packing);
+ * factor = scale[channel * sstride] (sstride 0: layer-wise stitching, one scalar) */
+int vmtl_pack_weights_scaled(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
+                             long long sr0, long long st, long long sc, int flip, const float* scale, int sstride,
+                             int smode, void* stream);
+/* weight gradient behind a folded stitch scale: slabs hold dL/d(W*s); grad <- dL/dW (torch layout (R0, C, T)),
+ * ds <- dL/ds (C entries, or one scalar when reduce_all) - the CrossStitchLayer weight gradient without a pass over
+ * activations; work: R0*C*T + C floats */
+int vmtl_unpack_weights_stitch(const float* packed, float* grad, const float* w, const float* scale, int sstride,
+                               float* ds, float* work, int R0, int T, int C, int Cs, int nslabs, long long slab_stride,
+                               int reduce_all, void* stream);
+/* batched form: descs = device array of n records {src*, dst*, i64 sr1, sr0, st, sc, start; scale*; i32 R1, R0, T, C,
+ * Cs, flip, sstride, smode} (vmtl_pack_desc_bytes() bytes each), start = first flat work index; total = sum R1*R0*T*Cs. */
 int vmtl_pack_desc_bytes(void);
 int vmtl_pack_weights_batch(const void* descs, int n, long long total, void* stream);
 int vmtl_pack_weights_slice(const float* src, float* dst, int R0, int T, int C, int group, long long sr0,

@@ -362,7 +362,9 @@ def test_bn_act_dwconv_returns_activation_for_a_second_consumer(dev, case):
 
 # B, C, H, W, Cout, act, bias
 BNPW_CASES = [(2, 16, 12, 20, 24, "relu", True), (1, 72, 8, 8, 24, "relu", False), (2, 128, 16, 16, 64, "relu", True),
-              (1, 240, 4, 8, 40, "hardswish", False), (2, 64, 9, 7, 130, "relu", True)]
+              (1, 240, 4, 8, 40, "hardswish", False), (2, 64, 9, 7, 130, "relu", True),
+              # large-M kernel with the staging prologue: 64x128, 256x32 and 64x64 tiles
+              (1, 128, 256, 256, 128, "relu", True), (4, 128, 256, 256, 32, "relu", True), (2, 128, 256, 256, 64, "relu", False)]
 
 
 @pytest.mark.gpu

@@ -35,6 +35,10 @@ CONV_CASES = [
     (4, 33, 112, 112, 33, 3, 1, 1, True),
     (4, 19, 112, 112, 20, 3, 1, 1, False),
     (2, 37, 160, 160, 67, 3, 1, 1, False),
+    # 1x1 at M = 65536+: the persistent large-M pointwise kernel (forward 64x128 tiles, data gradient 64x96 tiles)
+    (1, 192, 256, 256, 128, 1, 1, 0, True),
+    (1, 128, 300, 300, 32, 1, 1, 0, True),   # M = 90000 (ragged tile), N = 32: 256x32 tiles... needs M*ldy >= 2^23: no -> old kernel
+    (4, 128, 256, 256, 32, 1, 1, 0, False),  # M = 262144, N = 32: 256x32 tiles
 ]
 
 
@@ -604,6 +608,43 @@ def test_stitch(dev, channel_wise):
     assert float(off.abs().max()) == 0.0  # off-diagonal weights receive exactly zero gradient
 
 
+@pytest.mark.parametrize("channel_wise", [True, False])
+@pytest.mark.parametrize("case", [(2, 40, 9, 11, 24, 1, 0), (2, 37, 8, 12, 20, 3, 1)])
+def test_conv_with_folded_stitch_scale(dev, case, channel_wise):
+    """ops.conv2d(stitch=(w, task)) == conv(w[task, task, (c)] * x) (reference models/cross_stitch_model.py:32-37 followed
+    by the next conv of the CSNet walk): output, dx, the conv's weight gradient and the stitch layer's weight gradient
+    (diagonal entry of this task only; every other entry exactly zero) - the scale is folded into the packed operands
+    and its gradient comes out of the conv's weight-gradient slabs."""
+    ops = _ops()
+    B, Cin, H, W, Cout, K, pad = case
+    T, task = 2, 1
+    g = torch.Generator().manual_seed(321)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    sw = torch.rand((T, T, Cin) if channel_wise else (T, T), generator=g) + 0.25
+    xr, wr, swr = x.clone().requires_grad_(True), w.clone().requires_grad_(True), sw.clone().requires_grad_(True)
+    scale = swr[task, task].view(1, Cin, 1, 1) if channel_wise else swr[task, task]
+    yr = F.conv2d(scale * xr, wr, None, padding=pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd, swd = w.to(dev).requires_grad_(True), sw.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, None, stride=1, pad=pad, stitch=(swd, task))
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="stitched conv fwd")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, Cin), xr.grad, what="stitched conv dx")
+    assert_close(wd.grad.cpu(), wr.grad, what="stitched conv dW")
+    assert_close(swd.grad.cpu(), swr.grad, tol=2e-4, what="stitch weight gradient")
+    off = swd.grad.cpu().clone()
+    off[task, task] = 0
+    assert off.abs().max().item() == 0.0  # other tasks' / off-diagonal entries: exactly zero
+    # a changed stitch weight reaches the packed operand of the next call (pack-cache dependency on the factor)
+    with torch.no_grad():
+        swd.mul_(0.5)
+    y2 = ops.conv2d(xd.detach(), wd.detach(), None, stride=1, pad=pad, stitch=(swd, task))
+    assert_close(y2, 0.5 * y.detach(), tol=1e-5, what="stitched conv after an in-place update of the stitch weights")
+
+
 @pytest.mark.parametrize("C", [19, 14, 5])
 def test_cross_entropy(dev, C):
     ops = _ops()
@@ -698,7 +739,12 @@ def test_layout_roundtrip_and_adam(dev):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 6, 9, 7, 10, True), (1, 64, 128, 16, 24, 128, True), (3, 8, 3, 5, 11, 33, False),
-                                  (2, 128, 64, 8, 8, 64, True)])
+                                  (2, 128, 64, 8, 8, 64, True),
+                                  # large-M kernel (csrc/conv_pw.hip pw_big_kernel): 64x128 tiles K=192 two-source, data
+                                  # gradient 64x96 tiles two-destination; 64x64 tiles K=256 (two column tiles), data
+                                  # gradient 64x128 x 2 column tiles; K=64; a ragged last row tile
+                                  (1, 64, 128, 256, 256, 128, True), (1, 128, 128, 256, 256, 128, True),
+                                  (2, 32, 32, 256, 256, 128, False), (1, 64, 128, 257, 257, 100, True)])
 def test_conv1x1_cat_matches_conv_on_concat(dev, case):
     """ops.conv1x1_cat(xa, xb) == conv1x1(cat[xa, xb]) (MTAN attention conv1, reference models/mtan_model.py:57-59,
     139-141): output, BatchNorm partial rows, both input gradients, weight and bias gradients - the concat, the

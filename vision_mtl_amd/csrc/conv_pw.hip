@@ -297,17 +297,20 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // wave tile (TM*16) x (TN*16), WM x WN waves; KC = K chunks of 32 the instantiation can hold (Ks <= 32 * KC)
 template <int TM, int TN, int WM, int WN, int KC, bool SRC2, bool PRO>
-__global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
-  static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+  constexpr int NTHR = WM * WN * 64;
+  constexpr int SR = NTHR / 8;  // rows one staging pass covers (8 threads x 16 bytes = one 128-byte row chunk)
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int RA = BM / 32, RB = (BN + 31) / 32;  // staging rows per thread and chunk
+  static_assert(BM % SR == 0, "whole staging passes");
+  constexpr int RA = BM / SR, RB = (BN + SR - 1) / SR;  // staging rows per thread and chunk
   constexpr int OS = BN + 4;                         // output tile row stride (floats)
   constexpr int A_FLOATS = KC * BM * 32, O_FLOATS = BM * OS;
   constexpr int AO_FLOATS = A_FLOATS > O_FLOATS ? A_FLOATS : O_FLOATS;  // the output tile aliases the A image
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Bs = smem;                 // [KC][BN][32]
   float* As = smem + KC * BN * 32;  // [KC][BM][32]  | output tile [BM][OS]
-  f32x4* red = reinterpret_cast<f32x4*>(As + AO_FLOATS);  // [2][256]
+  f32x4* red = reinterpret_cast<f32x4*>(As + AO_FLOATS);  // [2][NTHR]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
   const int nkc = (p.Ks + 31) >> 5;   // K chunks in use (<= KC)
   const int nkg = (p.Ks + 15) >> 4;   // 16-wide k-groups in use
   const int r0 = tid >> 3, kq = tid & 7;
-  const int ks = (kq ^ (r0 & 7)) * 4;  // swizzled slot of this thread's k-quad ((r0 + 32 i) & 7 == r0 & 7)
+  const int ks = (kq ^ (r0 & 7)) * 4;  // swizzled slot of this thread's k-quad ((r0 + SR i) & 7 == r0 & 7)
   const int lda = SRC2 ? p.K1 : p.Ks;
 
   // ---- B: the whole [BN][Ks] weight tile, once ----
@@ -324,8 +327,8 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
   for (int c = 0; c < KC; ++c)
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int row = r0 + 32 * i, n = n0 + row, k = 32 * c + 4 * kq;
-      if (BN % 32 == 0 || row < BN) {
+      const int row = r0 + SR * i, n = n0 + row, k = 32 * c + 4 * kq;
+      if (BN % SR == 0 || row < BN) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < nkc && n < p.Nw && k < p.Ks) v = *reinterpret_cast<const f32x4*>(p.wp + (size_t)n * p.Ks + k);
         *reinterpret_cast<f32x4*>(Bs + (c * BN + row) * 32 + ks) = v;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
     }
   }
 
-  // ---- A tile prefetch: pre[c][i] = x[m0 + r0 + 32 i][32 c + 4 kq .. +3] ----
+  // ---- A tile prefetch: pre[c][i] = x[m0 + r0 + SR i][32 c + 4 kq .. +3] ----
   f32x4 pre[KC][RA];
   auto fetch = [&](int tile_m) {
     const int m0 = tile_m * BM;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
       const int k = 32 * c + 4 * kq;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + SR * i;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < nkc && m < p.M && k < p.Ks) {
           const float* src = (SRC2 && k >= p.K1) ? p.x2 + (size_t)m * (p.Ks - p.K1) + (k - p.K1) : p.x + (size_t)m * lda + k;
@@ -375,12 +378,12 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
             v = v * cpa[c] + cpc[c];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act_in);
-            const int m = m0 + r0 + 32 * i;
+            const int m = m0 + r0 + SR * i;
             if (p.a_out != nullptr && tile_n == 0 && m < p.M && k < p.Ks)
               *reinterpret_cast<f32x4*>(p.a_out + (size_t)m * p.Ks + k) = v;
             if (m >= p.M) v = (f32x4){0.f, 0.f, 0.f, 0.f};  // rows past M: act(pc) need not be 0
           }
-          *reinterpret_cast<f32x4*>(As + (c * BM + r0 + 32 * i) * 32 + ks) = v;
+          *reinterpret_cast<f32x4*>(As + (c * BM + r0 + SR * i) * 32 + ks) = v;
         }
       }
     }
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
 
   f32x4 acc[TM][TN];
   // epilogue geometry: thread <-> (row, column quad)
-  constexpr int Q = BN / 4, RPP = 256 / Q, PASSES = (BM + RPP - 1) / RPP;
+  constexpr int Q = BN / 4, RPP = NTHR / Q, PASSES = (BM + RPP - 1) / RPP;
   const int q = tid % Q, er0 = tid / Q;
   const int n4 = n0 + 4 * q;
   const bool ethread = er0 < RPP;
@@ -483,14 +486,14 @@ __global__ __launch_bounds__(256) void pw_big_kernel(PwP p, int nprog) {
           }
       }
       red[tid] = d1;
-      red[256 + tid] = d2;
+      red[NTHR + tid] = d2;
       lds_barrier();
       if (tid < Q && n4 < p.ldy) {  // er0 == 0: q == tid
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sc = sa;
 #pragma unroll
         for (int k = 0; k < RPP; ++k) {
           sa += red[tid + Q * k];
-          sc += red[256 + tid + Q * k];
+          sc += red[NTHR + tid + Q * k];
         }
         const float inv = 1.f / (float)nvalid;
         *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = pv + sa * inv;
@@ -519,8 +522,8 @@ static void pw_pick(int M, int ldy, int Ks, int* tn, int* kw) {
 //  id  wave tile x waves      BM x BN    KC (K <= 32 KC)
 //   0  <2,4> x 2x2            64 x 128   2, 4, 6
 //   1  <2,2> x 2x2            64 x 64    4, 8
-//   2  <4,2> x 4x1           256 x 32    4
 //   3  <2,3> x 2x2            64 x 96    4
+// (each also as an 8-wave workgroup - two waves per SIMD - with half the wave tile: VMTL_PW_BIG_WAVES)
 struct BigCfg { int id, bm, bn, kc; };
 static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
   static EnvInt e_on{"VMTL_PW_BIG", 1};  // tuning aid: 0 = every 1x1 conv on pw_gemm_kernel
@@ -531,8 +534,9 @@ static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
   const int kc = Ks <= 64 ? 2 : Ks <= 128 ? 4 : Ks <= 192 ? 6 : 8;
   BigCfg c;
   if (ldy <= 32) {
-    if (Ks > 128) return false;
-    c = {2, 256, 32, 4};
+    // 256 x 32 tiles measured SLOWER than pw_gemm_kernel on the one shape that would use them (M = 1 M, K = 128, N = 32
+    // with the staging prologue: 338 vs 312 us, both ~3.5 TB/s of a 1.15 GB launch)
+    return false;
   } else if (ldy <= 64) {
     c = {1, 64, 64, Ks <= 128 ? 4 : 8};
   } else if (Ks > 192) {
@@ -577,7 +581,8 @@ template <int TM, int TN, int WM, int WN, int KC>
 static int launch_pw_big(PwP& p, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int A_FLOATS = KC * BM * 32, O_FLOATS = BM * (BN + 4);
-  constexpr size_t lds = ((size_t)KC * BN * 32 + (A_FLOATS > O_FLOATS ? A_FLOATS : O_FLOATS)) * 4 + 2 * 256 * 16;
+  constexpr int NTHR = WM * WN * 64;
+  constexpr size_t lds = ((size_t)KC * BN * 32 + (A_FLOATS > O_FLOATS ? A_FLOATS : O_FLOATS)) * 4 + 2 * NTHR * 16;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.ldy, BN);
@@ -593,7 +598,7 @@ static int launch_pw_big(PwP& p, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
       attr_set = true;                                                                                                  \
     }                                                                                                                   \
-    hipLaunchKernelGGL((pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO>), grid, dim3(256), lds, st, p, nprog);             \
+    hipLaunchKernelGGL((pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO>), grid, dim3(NTHR), lds, st, p, nprog);            \
   }
   if (p.x2 != nullptr) VMTL_PW_BIG_LAUNCH(true, false)
   else if (p.pa != nullptr) VMTL_PW_BIG_LAUNCH(false, true)
@@ -603,13 +608,21 @@ static int launch_pw_big(PwP& p, hipStream_t st) {
 }
 
 static int pw_big_dispatch(PwP& p, const BigCfg& c, hipStream_t st) {
+  static EnvInt e_w8{"VMTL_PW_BIG_WAVES", 8};  // tuning aid: 4 = the 4-wave workgroups (one wave per SIMD)
+  const bool w8 = env_int(e_w8) == 8;
   switch (c.id) {
-    case 0:
+    case 0:  // 64 x 128
+      if (w8)
+        return c.kc == 2 ? launch_pw_big<2, 2, 2, 4, 2>(p, st) : c.kc == 4 ? launch_pw_big<2, 2, 2, 4, 4>(p, st)
+                                                                          : launch_pw_big<2, 2, 2, 4, 6>(p, st);
       return c.kc == 2 ? launch_pw_big<2, 4, 2, 2, 2>(p, st) : c.kc == 4 ? launch_pw_big<2, 4, 2, 2, 4>(p, st)
                                                                         : launch_pw_big<2, 4, 2, 2, 6>(p, st);
-    case 1: return c.kc == 4 ? launch_pw_big<2, 2, 2, 2, 4>(p, st) : launch_pw_big<2, 2, 2, 2, 8>(p, st);
-    case 2: return launch_pw_big<4, 2, 4, 1, 4>(p, st);
-    default: return launch_pw_big<2, 3, 2, 2, 4>(p, st);
+    case 1:  // 64 x 64
+      if (w8) return c.kc == 4 ? launch_pw_big<2, 1, 2, 4, 4>(p, st) : launch_pw_big<2, 1, 2, 4, 8>(p, st);
+      return c.kc == 4 ? launch_pw_big<2, 2, 2, 2, 4>(p, st) : launch_pw_big<2, 2, 2, 2, 8>(p, st);
+    default:  // 64 x 96
+      if (w8) return launch_pw_big<1, 3, 4, 2, 4>(p, st);
+      return launch_pw_big<2, 3, 2, 2, 4>(p, st);
   }
 }
 

@@ -15,9 +15,15 @@
 // Adam follows torch.optim.Adam (reference vision_mtl/training_lit.py:51,87).
 #include "common.h"
 
+// scale (nullable): a per-INPUT-channel factor folded into the operand - the cross-stitch scale of the tensor the conv
+// reads (reference models/cross_stitch_model.py:32-37: y[a] = w[a,a,(c)] * x[a], always followed by a dense conv in the
+// CSNet walk, :108-142): conv(W, s*x) = conv(W*s, x).  smode 1: the packed column channel c is the input channel
+// (forward layout), smode 2: the packed row r0 is (data-gradient layout); element scale[ch * sstride] (sstride 0: one
+// scalar for the layer).
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int R1,
                                                    int R0, int T, int C, int Cs, long long sr1, long long sr0,
-                                                   long long st, long long sc, int flip, long long total) {
+                                                   long long st, long long sc, int flip, long long total,
+                                                   const float* __restrict__ scale, int sstride, int smode) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cs);
@@ -27,7 +33,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
     const int r0 = (int)(rest % R0);
     const int r1 = (int)(rest / R0);
     const int t = flip ? T - 1 - tp : tp;
-    dst[i] = c < C ? src[r1 * sr1 + r0 * sr0 + t * st + c * sc] : 0.f;
+    float v = c < C ? src[r1 * sr1 + r0 * sr0 + t * st + c * sc] : 0.f;
+    if (smode != 0 && c < C) v *= scale[(size_t)(smode == 1 ? c : r0) * sstride];
+    dst[i] = v;
   }
 }
 
@@ -39,7 +47,9 @@ struct PackDesc {
   float* dst;
   long long sr1, sr0, st, sc;
   long long start;  // first flat work index of this descriptor
+  const float* scale;  // see pack_kernel (null: none)
   int R1, R0, T, C, Cs, flip;
+  int sstride, smode;
 };
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int n, long long total) {
@@ -60,7 +70,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
     const int r0 = (int)(rest % d.R0);
     const int r1 = (int)(rest / d.R0);
     const int t = d.flip ? d.T - 1 - tp : tp;
-    d.dst[j] = c < d.C ? d.src[r1 * d.sr1 + r0 * d.sr0 + t * d.st + c * d.sc] : 0.f;
+    float v = c < d.C ? d.src[r1 * d.sr1 + r0 * d.sr0 + t * d.st + c * d.sc] : 0.f;
+    if (d.smode != 0 && c < d.C) v *= d.scale[(size_t)(d.smode == 1 ? c : r0) * d.sstride];
+    d.dst[j] = v;
   }
 }
 
@@ -150,7 +162,20 @@ extern "C" int vmtl_pack_weights(const float* src, float* dst, int R1, int R0, i
   if (!src || !dst || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs) return VMTL_ERR_ARG;
   const long long total = (long long)R1 * R0 * T * Cs;
   hipLaunchKernelGGL(pack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, R1, R0, T, C, Cs,
-                     sr1, sr0, st, sc, flip, total);
+                     sr1, sr0, st, sc, flip, total, (const float*)nullptr, 0, 0);
+  return vmtl_check_launch();
+}
+
+// vmtl_pack_weights with the cross-stitch scale of the conv's input folded in (see pack_kernel): smode 1 / 2
+extern "C" int vmtl_pack_weights_scaled(const float* src, float* dst, int R1, int R0, int T, int C, int Cs, long long sr1,
+                                        long long sr0, long long st, long long sc, int flip, const float* scale,
+                                        int sstride, int smode, void* stream) {
+  VMTL_ENTER();
+  if (!src || !dst || !scale || R1 <= 0 || R0 <= 0 || T <= 0 || C <= 0 || C > Cs || (smode != 1 && smode != 2) || sstride < 0)
+    return VMTL_ERR_ARG;
+  const long long total = (long long)R1 * R0 * T * Cs;
+  hipLaunchKernelGGL(pack_kernel, dim3(pk_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, R1, R0, T, C, Cs,
+                     sr1, sr0, st, sc, flip, total, scale, sstride, smode);
   return vmtl_check_launch();
 }
 
@@ -175,6 +200,91 @@ extern "C" int vmtl_unpack_weights(const float* packed, float* grad, int R1, int
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(unpack_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, packed, grad, R1, R0, T, C, Cs,
                      sr1, sr0, st, sc, flip, nslabs, slab_stride, total);
+  return vmtl_check_launch();
+}
+
+// ---- weight gradient of a conv whose input carried a folded cross-stitch scale s (W' = W * s[ci] was the operand):
+// the slabs hold dL/dW'.  dL/dW[co][ci][t] = dL/dW' * s[ci];  dL/ds[ci] = sum_{co,t} dL/dW'[co][ci][t] * W[co][ci][t]
+// (the stitch layer's weight gradient, reference models/cross_stitch_model.py:32-37, without a pass over activations).
+// Step 1 (this kernel, the slab sum of unpack_kernel): grad = g' * s and prod = g' * W in the torch layout (Cout, Cin, T).
+__global__ __launch_bounds__(256) void unpack_stitch_kernel(const float* __restrict__ packed, float* __restrict__ grad,
+                                                            float* __restrict__ prod, const float* __restrict__ w,
+                                                            const float* __restrict__ scale, int sstride, int R0, int T,
+                                                            int C, int Cs, int nslabs, long long slab_stride,
+                                                            long long total) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+    const long long i = base + lane;  // torch index (r0 * C + c) * T + t
+    float s = 0.f;
+    int c = 0;
+    if (i < total) {
+      const int t = (int)(i % T);
+      long long rest = i / T;
+      c = (int)(rest % C);
+      const int r0 = (int)(rest / C);
+      const float* src = packed + ((size_t)r0 * T + t) * Cs + c;
+      for (int z = zg; z < nslabs; z += 4) s += src[(size_t)z * slab_stride];
+    }
+    red[zg][lane] = s;
+    __syncthreads();
+    if (zg == 0 && i < total) {
+      const float g = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+      grad[i] = g * scale[(size_t)c * sstride];
+      prod[i] = g * w[i];
+    }
+    __syncthreads();
+  }
+}
+
+// Step 2: ds[ci] = sum_{co,t} prod[co][ci][t] (one workgroup per input channel, fp64 accumulation);
+// reduce_all: one scalar = the sum over channels too (layer-wise stitching), through `tmp` [C]
+__global__ __launch_bounds__(256) void stitch_wsum_kernel(const float* __restrict__ prod, float* __restrict__ out, int R0,
+                                                          int C, int T) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double a = 0.0;
+  for (int j = threadIdx.x; j < R0 * T; j += 256) {
+    const int r0 = j / T, t = j - r0 * T;
+    a += (double)prod[((size_t)r0 * C + c) * T + t];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_vec_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ double sh[4];
+  double a = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) a += (double)v[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// packed: nslabs slabs [R0][T][Cs] (forward packing of a (R0 = Cout, C = Cin, T taps) conv weight); grad: dL/dW in the
+// torch layout; w: the weight; scale / sstride: the folded stitch factors; ds: their gradient (C entries, or ONE when
+// reduce_all); work: R0*C*T + C floats of scratch.
+extern "C" int vmtl_unpack_weights_stitch(const float* packed, float* grad, const float* w, const float* scale, int sstride,
+                                          float* ds, float* work, int R0, int T, int C, int Cs, int nslabs,
+                                          long long slab_stride, int reduce_all, void* stream) {
+  VMTL_ENTER();
+  if (!packed || !grad || !w || !scale || !ds || !work || R0 <= 0 || T <= 0 || C <= 0 || C > Cs || nslabs <= 0 || sstride < 0)
+    return VMTL_ERR_ARG;
+  if (slab_stride <= 0) slab_stride = (long long)R0 * T * Cs;
+  const long long total = (long long)R0 * C * T;
+  long long nb = cdivll(total, 64);
+  if (nb > 8192) nb = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(unpack_stitch_kernel, dim3((int)nb), dim3(256), 0, st, packed, grad, work, w, scale, sstride, R0, T, C,
+                     Cs, nslabs, slab_stride, total);
+  float* per_c = reduce_all ? work + total : ds;
+  hipLaunchKernelGGL(stitch_wsum_kernel, dim3(C), dim3(256), 0, st, work, per_c, R0, C, T);
+  if (reduce_all) hipLaunchKernelGGL(sum_vec_kernel, dim3(1), dim3(256), 0, st, per_c, C, ds);
   return vmtl_check_launch();
 }
 

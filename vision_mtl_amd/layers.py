@@ -58,16 +58,17 @@ def _pair(v):
     return v[0] if isinstance(v, (tuple, list)) else v
 
 
-def conv(x: Act, m: nn.Conv2d) -> Act:
-    """Dense conv (+bias), no normalisation."""
+def conv(x: Act, m: nn.Conv2d, stitch=None) -> Act:
+    """Dense conv (+bias), no normalisation.  stitch = (CrossStitchLayer.weights, task): the stitch scale of x, folded
+    into the conv's operands (ops.conv2d)."""
     if m.groups != 1:
         raise ValueError("conv(): use dwconv() for depthwise modules")
-    y = ops.conv2d(x.t, m.weight, m.bias, _pair(m.stride), _pair(m.padding))
+    y = ops.conv2d(x.t, m.weight, m.bias, _pair(m.stride), _pair(m.padding), stitch=stitch)
     return Act(y, m.out_channels)
 
 
 def conv_bn_act(x, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | None = None,
-                res: Act | None = None) -> Act:
+                res: Act | None = None, stitch=None) -> Act:
     """act(BN(conv(x))) [* mul] [+ res] with the BatchNorm column sums taken from the conv epilogue.
     x: an Act, or a pair (xa, xb) standing for torch.cat((xa, xb), dim=1): a 1x1 conv then reads both maps directly
     (ops.conv1x1_cat), anything else gets the materialised concat."""
@@ -83,9 +84,11 @@ def conv_bn_act(x, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int, mul: Act | None =
         x = cat(xa, xb)
     if c.groups == 1:
         out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train,
-                         zero_bias_grad=train and c.bias is not None)
+                         zero_bias_grad=train and c.bias is not None, stitch=stitch)
         y, stats = out if train else (out, None)
     else:
+        if stitch is not None:
+            raise ValueError("a stitch scale can only be folded into a dense conv")
         if c.groups != c.in_channels or c.in_channels != c.out_channels or c.bias is not None:
             raise ValueError("only depthwise grouped convs are supported")
         y, stats = ops.dwconv(x.t, c.weight, _pair(c.stride), _pair(c.padding)), None

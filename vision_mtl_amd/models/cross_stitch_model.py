@@ -12,6 +12,7 @@ corresponding HIP kernel; the walk is compiled once into a flat program.
 from __future__ import annotations
 
 import contextlib
+import os
 import re
 import typing as t
 
@@ -146,7 +147,24 @@ class CSNet(nn.Module):
                     continue
             fused.append(prog[i])
             i += 1
-        self._program = fused
+        # peephole 2: a stitch site directly in front of a dense conv (every site of the reference's walk is: the next
+        # leaf is a block's conv_pw / conv, or a decoder block's conv1) is FOLDED into that conv - the scale rides on the
+        # packed weights, its gradient comes out of the conv's weight-gradient slabs (ops._Conv2d): no stitch launch at all
+        folded, i = [], 0
+        fold_ok = os.environ.get("VMTL_STITCH_FOLD", "1") != "0"
+        while i < len(fused):
+            op, arg = fused[i]
+            if fold_ok and op == "stitch" and i + 1 < len(fused):
+                nop, narg = fused[i + 1]
+                conv_name = narg if nop == "leaf" else narg[0] if nop == "conv_bn_relu" else None
+                layer = get_module_by_name(first, conv_name) if conv_name else None
+                if isinstance(layer, nn.Conv2d) and layer.groups == 1:
+                    folded.append(("st_" + nop, (arg, narg)))
+                    i += 2
+                    continue
+            folded.append((op, arg))
+            i += 1
+        self._program = folded
 
     @staticmethod
     def _apply_leaf(layer: nn.Module, x: L.Act) -> L.Act:
@@ -196,10 +214,16 @@ class CSNet(nn.Module):
                         feats[task] = L.up2_cat(f, None)
                     elif op == "leaf":
                         feats[task] = self._apply_leaf(get_module_by_name(net, arg), f)
+                    elif op == "st_leaf":  # stitch scale folded into the conv that follows it
+                        feats[task] = L.conv(f, get_module_by_name(net, arg[1]), stitch=(self.cross_stitch_layers[arg[0]].weights, ti))
+                    elif op == "st_conv_bn_relu":
+                        c_, b_ = arg[1]
+                        feats[task] = L.conv_bn_act(f, get_module_by_name(net, c_), get_module_by_name(net, b_), ops.ACT_RELU,
+                                                    stitch=(self.cross_stitch_layers[arg[0]].weights, ti))
                     else:  # conv_bn_relu
                         feats[task] = L.conv_bn_act(f, get_module_by_name(net, arg[0]), get_module_by_name(net, arg[1]),
                                                     ops.ACT_RELU)
-                if self.debug_acts is not None and op in ("merge", "up", "conv_bn_relu"):
+                if self.debug_acts is not None and op in ("merge", "up", "conv_bn_relu", "st_conv_bn_relu"):
                     rec = [op, arg, task, L.to_nchw(feats[task]).detach().cpu(), None]
                     if feats[task].t.requires_grad:
                         C = feats[task].C

@@ -237,6 +237,8 @@ class _PackCache:
     @staticmethod
     def _alive(e):
         w = e["wref"]()
+        if "sref" in e and e["sref"]() is None:
+            return False
         return w is not None and w.data_ptr() == e["ptr"]
 
     def purge(self):
@@ -248,25 +250,38 @@ class _PackCache:
         if len(self.entries) + len(self.custom) != n:
             self.dirty = True
 
-    def get(self, weight, kind, params, offset=0, out=None):
+    def get(self, weight, kind, params, offset=0, out=None, scale=None):
         """params = (R1, R0, T, C, Cs, sr1, sr0, st, sc, flip); offset = first element of the weight to read;
-        out: destination for a NEW entry (a slice of a caller-owned persistent buffer, see shared())."""
+        out: destination for a NEW entry (a slice of a caller-owned persistent buffer, see shared());
+        scale = (tensor, first element, stride, smode): a cross-stitch factor folded into the operand
+        (vmtl_pack_weights_scaled) - the entry is then also invalidated by a change of that tensor."""
         key = (id(weight), kind, params, offset)
         e = self.entries.get(key)
         if e is not None and e["wref"]() is not weight:  # id() of a dead tensor reused by a new one
             e = None
-        if e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch:
+        sver = None if scale is None else (scale[0].data_ptr(), scale[0]._version, scale[1], scale[2], scale[3])
+        if (e is not None and e["ptr"] == weight.data_ptr() and e["version"] == weight._version and e["epoch"] == self.epoch
+                and e.get("sver") == sver):
             if e.get("side"):
                 self.join()  # packed on the side stream this step: wait for its event (no-op after the first time)
             return e["dst"]
         R1, R0, T, C, Cs = params[:5]
-        if e is None or e["ptr"] != weight.data_ptr() or (out is not None and e["dst"].data_ptr() != out.data_ptr()):
+        if (e is None or e["ptr"] != weight.data_ptr() or (out is not None and e["dst"].data_ptr() != out.data_ptr())
+                or (e.get("sver") or (None,))[0] != (sver or (None,))[0]):
             e = {"dst": _empty((R1 * R0, T * Cs), weight) if out is None else out, "params": params,
                  "wref": weakref.ref(weight), "ptr": weight.data_ptr(), "offset": offset}
+            if scale is not None:  # the table needs the factor's address; weak: the cache must not keep parameters alive
+                e["sref"], e["scale"] = weakref.ref(scale[0]), (scale[0].data_ptr() + 4 * scale[1], scale[2], scale[3])
             self.entries[key] = e
             self.dirty = True
-        pack(weight.view(-1)[offset:] if offset else weight, *params, out=e["dst"])
-        e["version"], e["epoch"] = weight._version, self.epoch
+        src = weight.view(-1)[offset:] if offset else weight
+        if scale is None:
+            pack(src, *params, out=e["dst"])
+        else:
+            R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = params
+            _k("vmtl_pack_weights_scaled", src=src, dst=e["dst"], R1=R1, R0=R0, T=T, C=C, Cs=Cs, sr1=sr1, sr0=sr0, st=st,
+               sc=sc, flip=flip, scale=scale[0].view(-1)[scale[1]:], sstride=scale[2], smode=scale[3])
+        e["version"], e["epoch"], e["sver"] = weight._version, self.epoch, sver
         return e["dst"]
 
     def shared(self, anchor, kind, shape):
@@ -320,8 +335,9 @@ class _PackCache:
             recs, start = [], 0
             for e in live:
                 R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
-                recs.append(struct.pack("<QQqqqqqiiiiii", e["ptr"] + 4 * e.get("offset", 0), e["dst"].data_ptr(), sr1, sr0,
-                                        st, sc, start, R1, R0, T, C, Cs, flip))
+                sptr, sstride, smode = e.get("scale", (0, 0, 0))
+                recs.append(struct.pack("<QQqqqqqQiiiiiiii", e["ptr"] + 4 * e.get("offset", 0), e["dst"].data_ptr(), sr1, sr0,
+                                        st, sc, start, sptr, R1, R0, T, C, Cs, flip, sstride, smode))
                 start += R1 * R0 * T * Cs
             size = lib().raw("vmtl_pack_desc_bytes")()
             blob = b"".join(r.ljust(size, b"\0") for r in recs)
@@ -359,6 +375,10 @@ class _PackCache:
             w = e["wref"]()
             if w is not None:
                 e["version"], e["epoch"] = w._version, self.epoch
+                if "sref" in e:  # the batched launch read the stitch factor as it is now
+                    sw = e["sref"]()
+                    if sw is not None and e.get("sver") is not None:
+                        e["sver"] = (sw.data_ptr(), sw._version) + tuple(e["sver"][2:])
         # the large operands and the ones with their own pack kernels (up2 phase / gradient matrices): none is needed
         # before the decoder, so they are built on the side stream while the encoder runs; get() / get_custom() make
         # the consuming stream wait for the event on first use
@@ -505,11 +525,26 @@ def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, 
 
 
 # ----------------------------------------------------------------------------- conv2d
+def _stitch_view(stitch_w, task, C):
+    """(first element, stride) of the diagonal w[task, task, (c)] inside the flattened CrossStitchLayer parameter
+    (reference models/cross_stitch_model.py:21-37: (T, T, C) channel-wise or (T, T) layer-wise)."""
+    T = stitch_w.shape[0]
+    if stitch_w.dim() == 3:
+        if stitch_w.shape[2] != C:
+            raise ValueError(f"stitched conv: the stitch layer has {stitch_w.shape[2]} channels, the conv reads {C}")
+        return (task * T + task) * C, 1
+    return task * T + task, 0
+
+
 class _Conv2d(torch.autograd.Function):
-    """y = conv2d(x, weight) (+ bias); weight stays in torch (Cout, Cin, KH, KW) layout."""
+    """y = conv2d(x, weight) (+ bias); weight stays in torch (Cout, Cin, KH, KW) layout.
+    stitch_w (optional): the CrossStitchLayer parameter whose diagonal entry of `stitch_task` scales x first
+    (y = conv(w[a,a,(c)] * x): reference models/cross_stitch_model.py:32-37 + the conv that follows every stitch site in
+    the CSNet walk :108-142).  The scale is FOLDED into the packed operands (forward and data gradient) and its weight
+    gradient is taken from the conv's own weight-gradient slabs: no pass over the activations for the stitch at all."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, want_stats, zero_bias_grad=False):
+    def forward(ctx, x, weight, bias, stride, pad, want_stats, zero_bias_grad=False, stitch_w=None, stitch_task=0):
         x = _req(x, "x")
         weight = _req(weight, "weight")
         B, H, W, Cs = x.shape
@@ -520,7 +555,13 @@ class _Conv2d(torch.autograd.Function):
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
         ldy = ceil4(Cout)
-        wp = packs.get(weight, "fwd", (1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, 0))
+        if stitch_w is None:
+            wp = packs.get(weight, "fwd", (1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, 0))
+        else:
+            stitch_w = _req(stitch_w, "stitch weights")
+            soff, sstride = _stitch_view(stitch_w, stitch_task, Cin)
+            wp = packs.get(weight, f"fwd_st{stitch_task}", (1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, 0),
+                           scale=(stitch_w, soff, sstride, 1))
         y = _empty((B, Ho, Wo, ldy), x)
         stats = None
         if want_stats and conv_ksplit(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad) > 1:
@@ -529,10 +570,11 @@ class _Conv2d(torch.autograd.Function):
             rows, _ = conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad)
             stats = _empty((rows, 2, ldy), x)
         _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Cout, Cout, KH, KW, stride, pad, cin=Cin)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, stitch_w)
         ctx.cfg = (stride, pad, bias is not None)
         ctx.zero_bias_grad = bool(zero_bias_grad)
         ctx.slots = (_slot(weight), _slot(bias))
+        ctx.stitch = (stitch_task, _slot(stitch_w))
         ctx.bias = bias
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" tensor for the stats output
         if want_stats:
@@ -542,35 +584,57 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
-        x, weight = ctx.saved_tensors
+        x, weight, stitch_w = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
+        stitch_task, stitch_slot = ctx.stitch
         if dy is None:
-            return None, None, None, None, None, None, None
+            return (None,) * 9
         dy = _req(dy, "dy")
         B, H, W, Cs = x.shape
         Cout, Cin, KH, KW = weight.shape
         KK = KH * KW
         _, Ho, Wo, ldy = dy.shape
-        dx = dw = db = None
+        dx = dw = db = dst_w = None
+        if stitch_w is not None:
+            soff, sstride = _stitch_view(stitch_w, stitch_task, Cin)
         stamp(f"main conv M={B * Ho * Wo} N={Cout} K={KK * Cin}")
         fork = side.mark()  # parameter gradients branch off here, before the data gradient
         if ctx.needs_input_grad[0]:
             if stride != 1:
                 raise NotImplementedError("data gradient of a strided dense conv is not on the hot path")
-            wd = packs.get(weight, "dgrad", (1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, 1))
+            if stitch_w is None:
+                wd = packs.get(weight, "dgrad", (1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, 1))
+            else:  # rows of the data-gradient operand are the input channels: d(x) = s * d(s * x)
+                wd = packs.get(weight, f"dgrad_st{stitch_task}", (1, Cin, KK, Cout, ldy, 0, KK, 1, Cin * KK, 1),
+                               scale=(stitch_w, soff, sstride, 2))
             dx = _empty((B, H, W, Cs), x)
             _conv_launch(dy, wd, None, dx, None, B, Ho, Wo, ldy, H, W, Cs, Cin, Cin, KH, KW, 1, KH - 1 - pad, cin=Cout)
-        if ctx.needs_input_grad[1]:
-            with side.branch(ctx.slots[0] is not None, B * Ho * Wo, fork, x, dy):
+        if ctx.needs_input_grad[1] or (stitch_w is not None and ctx.needs_input_grad[7]):
+            use_side = ctx.slots[0] is not None and (stitch_w is None or stitch_slot is not None)
+            with side.branch(use_side, B * Ho * Wo, fork, x, dy):
                 slabs, ns = _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Cout, KH, KW, stride, pad,
                                    2.0 * B * Ho * Wo * Cout * KK * Cin)
-                dw = unpack(slabs, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns)
+                if stitch_w is None:
+                    dw = unpack(slabs, weight.shape, 1, Cout, KK, Cin, Cs, 0, Cin * KK, 1, KK, out=ctx.slots[0], nslabs=ns)
+                else:
+                    # the slabs hold dL/d(W*s): dW = slabs * s, and the stitch weight's gradient is their contraction
+                    # with W (one small launch pair on the weight-sized tensor; off-diagonal entries stay zero)
+                    dw = _empty(weight.shape, x) if ctx.slots[0] is None else ctx.slots[0]
+                    n = Cin if sstride else 1
+                    if stitch_slot is not None:
+                        ds = stitch_slot.view(-1)[soff:soff + n]
+                    else:
+                        dst_w = torch.zeros_like(stitch_w)
+                        ds = dst_w.view(-1)[soff:soff + n]
+                    _k("vmtl_unpack_weights_stitch", packed=slabs, grad=dw, w=weight, scale=stitch_w.view(-1)[soff:],
+                       sstride=sstride, ds=ds, work=_empty((Cout * Cin * KK + Cin,), x), R0=Cout, T=KK, C=Cin, Cs=Cs,
+                       nslabs=ns, slab_stride=0, reduce_all=0 if sstride else 1)
                 stamp(f"side conv M={B * Ho * Wo} N={Cout} K={KK * Cin}")
             if ctx.slots[0] is not None:
                 dw = None
         if has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(ctx.bias, ctx.slots[1], dy, B * Ho * Wo, Cout, ldy, ctx.zero_bias_grad, fork)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, dst_w, None
 
 
 class _BNActPw(torch.autograd.Function):
@@ -1063,9 +1127,11 @@ def up2_conv(xl, C0, skip, weight, want_stats=False):
     return y, stats
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False, zero_bias_grad=False):
-    """zero_bias_grad: the caller normalises y with a TRAIN-mode BatchNorm next, which makes dL/dbias exactly zero."""
-    y, stats = _Conv2d.apply(x, weight, bias, stride, pad, want_stats, zero_bias_grad)
+def conv2d(x, weight, bias=None, stride=1, pad=0, want_stats=False, zero_bias_grad=False, stitch=None):
+    """zero_bias_grad: the caller normalises y with a TRAIN-mode BatchNorm next, which makes dL/dbias exactly zero.
+    stitch = (CrossStitchLayer weights, task index): y = conv(w[task, task, (c)] * x), the scale folded into the operand."""
+    y, stats = _Conv2d.apply(x, weight, bias, stride, pad, want_stats, zero_bias_grad,
+                             None if stitch is None else stitch[0], 0 if stitch is None else int(stitch[1]))
     if stats is not None:  # pixels per statistics row, for whoever finalizes them (bn_act)
         stats._vmtl_rpb = conv_stats_geometry(y.shape[0], y.shape[1], y.shape[2], x.shape[3], y.shape[3], weight.shape[2],
                                               weight.shape[3], stride, pad)[1]
