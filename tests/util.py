@@ -47,6 +47,7 @@ def assert_grads_as_good_as_fp32_cpu(named_hip, g64, g32, floor=5e-2, whole_floo
     fp64 run of itself (basic: 3e-3..6e-3).  Hence: per tensor, rel-L2 error vs the fp64 gradient
     <= max(floor, factor x the fp32 CPU oracle's own error); whole gradient <= max(whole_floor, 2 x)."""
     num = den = num32 = 0.0
+    worst = (0.0, 0.0, "")
     gmax = max(float(v.abs().max()) for v in g64.values())
     for k, g in named_hip.items():
         ref = g64[k]
@@ -55,11 +56,15 @@ def assert_grads_as_good_as_fp32_cpu(named_hip, g64, g32, floor=5e-2, whole_floo
             continue
         eh, ec = rel_l2(g, ref), rel_l2(g32[k], ref)
         assert eh <= max(floor, factor * ec), f"grad {k}: rel-L2 error {eh:.2e} (fp32 CPU oracle: {ec:.2e})"
+        if eh > worst[0]:
+            worst = (eh, ec, k)
         num += float((g.double() - ref.double()).pow(2).sum())
         num32 += float((g32[k].double() - ref.double()).pow(2).sum())
         den += float(ref.double().pow(2).sum())
     tot, tot32 = (num / den) ** 0.5, (num32 / den) ** 0.5
     assert tot <= max(whole_floor, 2.0 * tot32), f"whole-gradient rel-L2 error {tot:.2e} (fp32 CPU oracle: {tot32:.2e})"
+    print(f"gradient bar: worst tensor {worst[2]} rel-L2 {worst[0]:.2e} (fp32 CPU oracle {worst[1]:.2e}); whole gradient "
+          f"{tot:.2e} (fp32 CPU oracle {tot32:.2e})")
     return tot, tot32
 
 
