@@ -402,6 +402,12 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
       if (n4 + e < p.Nw) bias4[e] = p.bias[n4 + e];
   }
 
+  // BatchNorm partials: ONE statistics row per workgroup when every workgroup walks the same number of full tiles
+  // (shifted sums around the pivot of its first tile, kept per thread across tiles and folded once at the end): M = 1 M
+  // rows are 256 statistics rows instead of 16384 (the finalize kernel read 17 MB of partials per such layer), and the
+  // per-tile reduction barrier disappears.  Otherwise one row per tile.
+  const bool acc_stats = p.stats != nullptr && p.M % BM == 0 && p.tiles_m % nprog == 0;
+  f32x4 pv_acc = {0.f, 0.f, 0.f, 0.f}, d1_acc = pv_acc, d2_acc = pv_acc;
   int tile_m = blockIdx.x;
   if (tile_m < p.tiles_m) fetch(tile_m);
   bool first = true;
@@ -409,6 +415,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
     // tile_m's rows are in `pre` (in flight or landed): LDS image is free (first tile: B stores above need the barrier too)
     stage(tile_m);
     lds_barrier();
+    const bool first_tile = first;
     first = false;
     const int next = tile_m + nprog;
     if (next < p.tiles_m) fetch(next);  // stays in flight under the K loop, the epilogue and its stores
@@ -468,7 +475,23 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
         val[ps] = v;
       }
     }
-    if (p.stats != nullptr) {
+    if (acc_stats) {
+      if (ethread) {
+        if (first_tile) {
+          pv_acc = *reinterpret_cast<const f32x4*>(tile + 4 * q) + bias4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n4 + e >= p.Cout) pv_acc[e] = 0.f;
+        }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+          if (er0 + ps * RPP < BM) {
+            const f32x4 d = val[ps] - pv_acc;
+            d1_acc += d;
+            d2_acc += d * d;
+          }
+      }
+    } else if (p.stats != nullptr) {
       // shifted sums around the column's value in the tile's first row (accurate when |mean| >> std)
       const int nvalid = min(BM, p.M - m0);
       f32x4 pv = {0.f, 0.f, 0.f, 0.f}, d1 = pv, d2 = pv;
@@ -501,6 +524,30 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
       }
     }
     lds_barrier();  // the output tile has been read: the region takes the next A image
+  }
+  if (acc_stats && blockIdx.x < p.tiles_m) {
+    // every thread of a column (q) used the SAME pivot: the one thread er0 == 0 read from the first tile's row 0 is not
+    // shared - broadcast it through LDS first
+    if (ethread && er0 == 0) red[tid] = pv_acc;
+    lds_barrier();
+    const f32x4 pv = ethread ? red[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    lds_barrier();
+    // a thread's sums are around ITS pivot only if its pivot equals the column's: all threads of a column loaded the same
+    // tile row 0, so pv_acc == pv bit for bit (same LDS value, same bias) - nothing to re-centre
+    red[tid] = d1_acc;
+    red[NTHR + tid] = d2_acc;
+    lds_barrier();
+    if (tid < Q && n4 < p.ldy) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sc = sa;
+#pragma unroll
+      for (int k = 0; k < RPP; ++k) {
+        sa += red[tid + Q * k];
+        sc += red[NTHR + tid + Q * k];
+      }
+      const float inv = 1.f / (float)((p.tiles_m / nprog) * BM);
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + n4) = pv + sa * inv;
+      *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + n4) = sc - sa * sa * inv;
+    }
   }
   (void)first;
 }
@@ -553,9 +600,22 @@ static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
 
 // variant 0: forward-type launches (vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad); 1: launches that always run on
 // pw_gemm_kernel (BatchNorm-backward epilogue, residual operand)
+static int pw_num_cus();
+
+// programs (persistent workgroups per column tile) of the large-M kernel for this problem
+static int pw_big_nprog(int M, int ldy, const BigCfg& c) {
+  const int tiles_m = cdiv(M, c.bm), tiles_n = cdiv(ldy, c.bn);
+  int nprog = pw_num_cus() / tiles_n;
+  if (nprog < 1) nprog = 1;
+  return nprog > tiles_m ? tiles_m : nprog;
+}
+
 extern "C" int vmtl_conv1x1_stats_block(int M, int ldy, int Ks, int variant) {
   BigCfg c;
-  if (variant == 0 && pw_big_cfg(M, ldy, Ks, &c)) return c.bm;
+  if (variant == 0 && pw_big_cfg(M, ldy, Ks, &c)) {
+    const int tiles_m = cdiv(M, c.bm), nprog = pw_big_nprog(M, ldy, c);
+    return (M % c.bm == 0 && tiles_m % nprog == 0) ? (tiles_m / nprog) * c.bm : c.bm;  // one row per workgroup / per tile
+  }
   int tn, kw;
   pw_pick(M, ldy, Ks, &tn, &kw);
   return (4 / kw) * 32;
@@ -586,9 +646,8 @@ static int launch_pw_big(PwP& p, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.ldy, BN);
-  int nprog = pw_num_cus() / p.tiles_n;
-  if (nprog < 1) nprog = 1;
-  if (nprog > p.tiles_m) nprog = p.tiles_m;
+  const BigCfg cfg = {0, BM, BN, KC};
+  const int nprog = pw_big_nprog(p.M, p.ldy, cfg);
   const dim3 grid(nprog, p.tiles_n);
 #define VMTL_PW_BIG_LAUNCH(SRC2, PRO)                                                                                   \
   {                                                                                                                     \
