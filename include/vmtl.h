@@ -64,9 +64,9 @@ int vmtl_conv2d_stats_block(int B, int Ho, int Wo, int ldy); /* output rows per 
  * fragments straight from global memory, K split over the waves of a workgroup when the tile grid is small
  * (csrc/conv_pw.hip).  stats (optional): [vmtl_conv1x1_stats_rows][2][ldy] per-row-block (mean, M2) of y,
  * vmtl_conv1x1_stats_block rows each. */
-/* variant 0: forward-type launches (vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad; large problems run on the
- * persistent large-M kernel, whose row block differs); 1: launches with a BatchNorm-backward epilogue or a residual
- * operand (vmtl_conv1x1_bnbwd*, vmtl_conv1x1_bn_res_fwd) */
+/* variant 0: vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad / _bnbwd (large problems run on the persistent large-M
+ * kernel, whose row block differs); 1: launches with a residual operand or an addend (vmtl_conv1x1_bn_res_fwd,
+ * vmtl_conv1x1_bnbwd_add: always the fragment-from-global kernel) */
 int vmtl_conv1x1_stats_block(int M, int ldy, int Ks, int variant);
 int vmtl_conv1x1_stats_rows(int M, int ldy, int Ks, int variant);
 int vmtl_conv1x1_fwd(const float* x, const float* wp, const float* bias, float* y, float* stats, int M, int Ks, int ldy,

@@ -20,7 +20,7 @@ import torch  # noqa: F401
 
 _PKG = Path(__file__).resolve().parent
 CSRC = _PKG / "csrc"
-LIB_PATH = CSRC / "libvmtl.so"
+LIB_PATH = Path(os.environ["VMTL_LIB"]) if os.environ.get("VMTL_LIB") else CSRC / "libvmtl.so"  # VMTL_LIB: A/B another build
 HEADER = _PKG.parent / "include" / "vmtl.h"
 
 _CTYPES = {

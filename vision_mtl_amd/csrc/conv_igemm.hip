@@ -381,6 +381,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * LDT + so);
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 16 * LDT + so);
+#ifdef VMTL_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -388,6 +391,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+#ifdef VMTL_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (NT > 0) {
         // tail weight rows BNM + t (wave-uniform row, per-quarter k slot): 4 distinct LDS addresses
 #pragma unroll
@@ -913,11 +919,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
       for (int i = 0; i < TM; ++i) fa[i] = ys[4 * s * LDY + i * 16];
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = xs[4 * s * LDX + j * 16];
+#ifdef VMTL_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#ifdef VMTL_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (NTR > 0) {  // dY[pixel 4s+lq][BMM .. BMM+3]: one 16-byte LDS read, broadcast within the quarter
         const f32x4 ty = *reinterpret_cast<const f32x4*>(Ys + cb * BP * LDY + (4 * s + lq) * LDY + BMM);
 #pragma unroll

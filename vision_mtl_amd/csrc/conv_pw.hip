@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // wave tile (TM*16) x (TN*16), WM x WN waves; KC = K chunks of 32 the instantiation can hold (Ks <= 32 * KC)
-template <int TM, int TN, int WM, int WN, int KC, bool SRC2, bool PRO>
+// EZ: BatchNorm-backward epilogue (see PwP::ez_x; no addend): dz = acc * act'(gamma * xhat + beta) and (sum dz, sum dz * xhat);
+// the ez_x values of a tile's epilogue are prefetched one tile ahead like A.
+template <int TM, int TN, int WM, int WN, int KC, bool SRC2, bool PRO, bool EZ = false>
 __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   constexpr int NTHR = WM * WN * 64;
@@ -402,6 +404,28 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
       if (n4 + e < p.Nw) bias4[e] = p.bias[n4 + e];
   }
 
+  // EZ: per-column constants of this thread's quad, and the ez_x prefetch registers (next tile / current tile)
+  f32x4 e_mean = {0.f, 0.f, 0.f, 0.f}, e_is = e_mean, e_g = e_mean, e_b = e_mean;
+  f32x4 ez_next[EZ ? PASSES : 1], ez_cur[EZ ? PASSES : 1];
+  if (EZ && ethread && n4 < p.ldy) {
+    e_mean = *reinterpret_cast<const f32x4*>(p.ez_mean + n4);
+    e_is = *reinterpret_cast<const f32x4*>(p.ez_invstd + n4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      e_g[e] = n4 + e < p.Cout ? (p.ez_gamma ? p.ez_gamma[n4 + e] : 1.f) : 0.f;
+      e_b[e] = n4 + e < p.Cout ? (p.ez_beta ? p.ez_beta[n4 + e] : 0.f) : 0.f;
+    }
+  }
+  auto fetch_ez = [&](int tm) {
+    if (EZ) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int r = er0 + ps * RPP, m = tm * BM + r;
+        ez_next[ps] = (ethread && r < BM && m < p.M && n4 < p.ldy) ? *reinterpret_cast<const f32x4*>(p.ez_x + (size_t)m * p.ldy + n4)
+                                                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
   // BatchNorm partials: ONE statistics row per workgroup when every workgroup walks the same number of full tiles
   // (shifted sums around the pivot of its first tile, kept per thread across tiles and folded once at the end): M = 1 M
   // rows are 256 statistics rows instead of 16384 (the finalize kernel read 17 MB of partials per such layer), and the
@@ -409,16 +433,26 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
   const bool acc_stats = p.stats != nullptr && p.M % BM == 0 && p.tiles_m % nprog == 0;
   f32x4 pv_acc = {0.f, 0.f, 0.f, 0.f}, d1_acc = pv_acc, d2_acc = pv_acc;
   int tile_m = blockIdx.x;
-  if (tile_m < p.tiles_m) fetch(tile_m);
+  if (tile_m < p.tiles_m) {
+    fetch(tile_m);
+    fetch_ez(tile_m);
+  }
   bool first = true;
   for (; tile_m < p.tiles_m; tile_m += nprog) {
     // tile_m's rows are in `pre` (in flight or landed): LDS image is free (first tile: B stores above need the barrier too)
     stage(tile_m);
+    if (EZ) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) ez_cur[ps] = ez_next[ps];  // fetched a whole tile ago
+    }
     lds_barrier();
     const bool first_tile = first;
     first = false;
     const int next = tile_m + nprog;
-    if (next < p.tiles_m) fetch(next);  // stays in flight under the K loop, the epilogue and its stores
+    if (next < p.tiles_m) {  // stays in flight under the K loop, the epilogue and its stores
+      fetch(next);
+      fetch_ez(next);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -455,6 +489,7 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
     // ---- epilogue: bias, pad zeros, coalesced float4 stores, per-tile (mean, M2) ----
     const int m0 = tile_m * BM;
     f32x4 val[PASSES];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2x = s1;  // EZ: this tile's (sum dz, sum dz * xhat) of the thread's rows
     if (ethread) {
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) {
@@ -465,6 +500,14 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (n4 + e >= p.Cout) v[e] = 0.f;
+          if (EZ && n4 < p.ldy) {
+            const f32x4 xh = (ez_cur[ps] - e_mean) * e_is;
+            const f32x4 z = e_g * xh + e_b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], p.ez_act);
+            s1 += v;
+            s2x += v * xh;
+          }
           const int m = m0 + r;
           if (n4 < p.ldy) {
             if (p.y2 == nullptr) *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + n4) = v;
@@ -475,7 +518,27 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
         val[ps] = v;
       }
     }
-    if (acc_stats) {
+    if (EZ && p.stats != nullptr) {
+      // plain column sums (sum dz, sum dz * xhat): per workgroup across its tiles, or per tile
+      d1_acc += s1;
+      d2_acc += s2x;
+      if (!acc_stats) {
+        red[tid] = d1_acc;
+        red[NTHR + tid] = d2_acc;
+        d1_acc = d2_acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lds_barrier();
+        if (tid < Q && n4 < p.ldy) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sc = sa;
+#pragma unroll
+          for (int k = 0; k < RPP; ++k) {
+            sa += red[tid + Q * k];
+            sc += red[NTHR + tid + Q * k];
+          }
+          *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 0) * p.ldy + n4) = sa;
+          *reinterpret_cast<f32x4*>(p.stats + ((size_t)tile_m * 2 + 1) * p.ldy + n4) = sc;
+        }
+      }
+    } else if (acc_stats) {
       if (ethread) {
         if (first_tile) {
           pv_acc = *reinterpret_cast<const f32x4*>(tile + 4 * q) + bias4;
@@ -545,8 +608,13 @@ __global__ __launch_bounds__(WM* WN * 64) void pw_big_kernel(PwP p, int nprog) {
         sc += red[NTHR + tid + Q * k];
       }
       const float inv = 1.f / (float)((p.tiles_m / nprog) * BM);
-      *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + n4) = pv + sa * inv;
-      *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + n4) = sc - sa * sa * inv;
+      if (EZ) {  // plain sums
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + n4) = sa;
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + n4) = sc;
+      } else {
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 0) * p.ldy + n4) = pv + sa * inv;
+        *reinterpret_cast<f32x4*>(p.stats + ((size_t)blockIdx.x * 2 + 1) * p.ldy + n4) = sc - sa * sa * inv;
+      }
     }
   }
   (void)first;
@@ -598,8 +666,8 @@ static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
   return true;
 }
 
-// variant 0: forward-type launches (vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad); 1: launches that always run on
-// pw_gemm_kernel (BatchNorm-backward epilogue, residual operand)
+// variant 0: launches that may run on the large-M kernel (vmtl_conv1x1_fwd / _cat_fwd / _bn_fwd / _cat_dgrad / _bnbwd);
+// 1: launches that always run on pw_gemm_kernel (residual operand, BatchNorm-backward epilogue with an addend)
 static int pw_num_cus();
 
 // programs (persistent workgroups per column tile) of the large-M kernel for this problem
@@ -649,19 +717,20 @@ static int launch_pw_big(PwP& p, hipStream_t st) {
   const BigCfg cfg = {0, BM, BN, KC};
   const int nprog = pw_big_nprog(p.M, p.ldy, cfg);
   const dim3 grid(nprog, p.tiles_n);
-#define VMTL_PW_BIG_LAUNCH(SRC2, PRO)                                                                                   \
+#define VMTL_PW_BIG_LAUNCH(SRC2, PRO, EZ)                                                                               \
   {                                                                                                                     \
     static bool attr_set = false;                                                                                       \
     if (!attr_set) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO>),           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO, EZ>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
       attr_set = true;                                                                                                  \
     }                                                                                                                   \
-    hipLaunchKernelGGL((pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO>), grid, dim3(NTHR), lds, st, p, nprog);            \
+    hipLaunchKernelGGL((pw_big_kernel<TM, TN, WM, WN, KC, SRC2, PRO, EZ>), grid, dim3(NTHR), lds, st, p, nprog);        \
   }
-  if (p.x2 != nullptr) VMTL_PW_BIG_LAUNCH(true, false)
-  else if (p.pa != nullptr) VMTL_PW_BIG_LAUNCH(false, true)
-  else VMTL_PW_BIG_LAUNCH(false, false)
+  if (p.ez_x != nullptr) VMTL_PW_BIG_LAUNCH(false, false, true)
+  else if (p.x2 != nullptr) VMTL_PW_BIG_LAUNCH(true, false, false)
+  else if (p.pa != nullptr) VMTL_PW_BIG_LAUNCH(false, true, false)
+  else VMTL_PW_BIG_LAUNCH(false, false, false)
 #undef VMTL_PW_BIG_LAUNCH
   return vmtl_check_launch();
 }
@@ -705,7 +774,7 @@ static void pw_plain(PwP& p) {  // no prologue, ordinary epilogue
 
 static int pw_dispatch(PwP& p, hipStream_t st) {
   BigCfg c;
-  if (p.ez_x == nullptr && p.res == nullptr && pw_big_cfg(p.M, p.ldy, p.Ks, &c)) return pw_big_dispatch(p, c, st);
+  if (p.ez_add == nullptr && p.res == nullptr && pw_big_cfg(p.M, p.ldy, p.Ks, &c)) return pw_big_dispatch(p, c, st);
   int tn, kw;
   pw_pick(p.M, p.ldy, p.Ks, &tn, &kw);
   if (tn == 2) return kw == 4 ? launch_pw<2, 4>(p, st) : launch_pw<2, 1>(p, st);

@@ -703,7 +703,7 @@ class _BNActPw(torch.autograd.Function):
         dgamma = _empty((C,), x) if sg is None else sg
         dbeta = _empty((C,), x) if sb is None else sb
         dz = _empty(x.shape, x)
-        rows = lib().raw("vmtl_conv1x1_stats_rows")(M, Cs, ldy, 1)
+        rows = lib().raw("vmtl_conv1x1_stats_rows")(M, Cs, ldy, 0 if d_a is None else 1)
         part = _empty((rows, 2, Cs), x)
         if d_a is None:
             _k("vmtl_conv1x1_bnbwd", _flop=2.0 * M * Cin * Cout, dy=dy, wp=wd, dz=dz, stats=part, ez_x=x, ez_mean=mean,
