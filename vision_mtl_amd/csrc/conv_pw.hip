@@ -637,6 +637,7 @@ static void pw_pick(int M, int ldy, int Ks, int* tn, int* kw) {
 //  id  wave tile x waves      BM x BN    KC (K <= 32 KC)
 //   0  <2,4> x 2x2            64 x 128   2, 4, 6
 //   1  <2,2> x 2x2            64 x 64    4, 8
+//   2  <1,1> x 4x2 (8 waves)  64 x 32    4
 //   3  <2,3> x 2x2            64 x 96    4
 // (each also as an 8-wave workgroup - two waves per SIMD - with half the wave tile: VMTL_PW_BIG_WAVES)
 struct BigCfg { int id, bm, bn, kc; };
@@ -649,9 +650,10 @@ static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
   const int kc = Ks <= 64 ? 2 : Ks <= 128 ? 4 : Ks <= 192 ? 6 : 8;
   BigCfg c;
   if (ldy <= 32) {
-    // 256 x 32 tiles measured SLOWER than pw_gemm_kernel on the one shape that would use them (M = 1 M, K = 128, N = 32
-    // with the staging prologue: 338 vs 312 us, both ~3.5 TB/s of a 1.15 GB launch)
-    return false;
+    // (4-wave 256 x 32 tiles measured SLOWER than pw_gemm_kernel on the one shape that uses this row - M = 1 M, K = 128,
+    // N = 32 with the staging prologue: 338 vs 312 us; now 64 x 32 tiles, 8 waves, two workgroups per CU)
+    if (Ks > 128) return false;
+    c = {2, 64, 32, 4};
   } else if (ldy <= 64) {
     c = {1, 64, 64, Ks <= 128 ? 4 : 8};
   } else if (Ks > 192) {
@@ -670,10 +672,15 @@ static bool pw_big_cfg(int M, int ldy, int Ks, BigCfg* out) {
 // 1: launches that always run on pw_gemm_kernel (residual operand, BatchNorm-backward epilogue with an addend)
 static int pw_num_cus();
 
-// programs (persistent workgroups per column tile) of the large-M kernel for this problem
+// programs (persistent workgroups per column tile) of the large-M kernel for this problem: one per CU, two where the LDS
+// images of two workgroups fit a CU (their staging / epilogue phases then overlap the other's K loop)
 static int pw_big_nprog(int M, int ldy, const BigCfg& c) {
   const int tiles_m = cdiv(M, c.bm), tiles_n = cdiv(ldy, c.bn);
-  int nprog = pw_num_cus() / tiles_n;
+  const int a_floats = c.kc * c.bm * 32, o_floats = c.bm * (c.bn + 4);
+  const long long lds = ((long long)c.kc * c.bn * 32 + (a_floats > o_floats ? a_floats : o_floats)) * 4 + 2 * 512 * 16;
+  static EnvInt e_occ{"VMTL_PW_BIG_OCC", 2};  // tuning aid
+  const int occ = (2 * lds <= 160 * 1024 && env_int(e_occ) >= 2) ? 2 : 1;
+  int nprog = occ * pw_num_cus() / tiles_n;
   if (nprog < 1) nprog = 1;
   return nprog > tiles_m ? tiles_m : nprog;
 }
@@ -714,7 +721,7 @@ static int launch_pw_big(PwP& p, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.ldy, BN);
-  const BigCfg cfg = {0, BM, BN, KC};
+  const BigCfg cfg = {0, BM, BN, KC};  // (LDS bytes in pw_big_nprog assume the 8-wave reduction scratch: an upper bound for 4 waves)
   const int nprog = pw_big_nprog(p.M, p.ldy, cfg);
   const dim3 grid(nprog, p.tiles_n);
 #define VMTL_PW_BIG_LAUNCH(SRC2, PRO, EZ)                                                                               \
@@ -748,6 +755,8 @@ static int pw_big_dispatch(PwP& p, const BigCfg& c, hipStream_t st) {
     case 1:  // 64 x 64
       if (w8) return c.kc == 4 ? launch_pw_big<2, 1, 2, 4, 4>(p, st) : launch_pw_big<2, 1, 2, 4, 8>(p, st);
       return c.kc == 4 ? launch_pw_big<2, 2, 2, 2, 4>(p, st) : launch_pw_big<2, 2, 2, 2, 8>(p, st);
+    case 2:  // 64 x 32 (8 waves only)
+      return launch_pw_big<1, 1, 4, 2, 4>(p, st);
     default:  // 64 x 96
       if (w8) return launch_pw_big<1, 3, 4, 2, 4>(p, st);
       return launch_pw_big<2, 3, 2, 2, 4>(p, st);
