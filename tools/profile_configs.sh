@@ -47,4 +47,4 @@ for cfg in $CONFIGS; do
   echo "== $cfg done" >&2
 done
 # gpurun only brings gpurun_out/ back: keep a copy of the summaries there
-mkdir -p $ROOT/gpurun_out/profiles_$ROUND && cp $ROOT/profiles/${ROUND}_* $ROOT/gpurun_out/profiles_$ROUND/
+mkdir -p $ROOT/gpurun_out/profiles_$ROUND && cp $ROOT/profiles/${ROUND}_*.* $ROOT/gpurun_out/profiles_$ROUND/
