@@ -155,7 +155,7 @@ def test_conv2d_bf16x3_operand_split(dev, tile, vmtl_env):
     assert_close(out["1"][2], out["0"][2], tol=1e-5, atol=1e-6, what="BatchNorm partials under bf16x3")
 
 
-@pytest.mark.parametrize("rows", [16, 32, 48, 64, 80, 144, 20, 36, 68])
+@pytest.mark.parametrize("rows", [16, 32, 48, 64, 80, 144, 20, 36, 68, 128])
 def test_conv2d_wgrad_every_row_config(dev, rows, vmtl_env):
     """Each weight-gradient tile height (incl. the VALU tail-row ones) forced through the tuning override."""
     ops = _ops()

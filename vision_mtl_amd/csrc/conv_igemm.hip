@@ -1358,16 +1358,18 @@ static int wgrad_rows(int Nw) {
   // a 16- or 32-row tile issues 3-4 LDS reads per 2-4 MFMAs and loses to a taller, slightly more
   // padded one (measured: Nw=270 as 17x16 rows ran at 42 TF, as 2x144 at ~90 TF).
   // 20 / 36 / 68 = 16 / 32 / 64 MFMA rows + 4 tail rows on the VALU
-  static const int cands[] = {16, 32, 48, 64, 80, 144, 20, 36, 68};
-  static const float eff[] = {0.35f, 0.55f, 0.72f, 0.82f, 0.88f, 1.0f, 0.43f, 0.61f, 0.86f};
+  // 128 rows (round 3): N = 128 / 256 / 512 (MTAN's widths) padded to 144-row tiles wasted 11 % of the MFMAs
+  static const int cands[] = {16, 32, 48, 64, 80, 144, 20, 36, 68, 128};
+  static const float eff[] = {0.35f, 0.55f, 0.72f, 0.82f, 0.88f, 1.0f, 0.43f, 0.61f, 0.86f, 0.97f};
+  constexpr int NC = 10;
   static EnvInt force{"VMTL_FORCE_WG_ROWS", 0};  // tuning aid
   if (const int v = env_int(force)) {
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < NC; ++i)
       if (cands[i] == v) return v;
   }
   int best = 16;
   float bc = -1.f;
-  for (int i = 0; i < 9; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const float cost = (float)((long long)cdiv(Nw, cands[i]) * cands[i]) / eff[i];
     if (bc < 0.f || cost < bc) {
       best = cands[i];
@@ -1434,7 +1436,7 @@ static int wgrad_splits_uncached(int M, int Nw, int Ktot) {
   const int rows = wgrad_rows(Nw);
   int occ = 160 * 1024 / wgrad_lds_bytes(rows);
   if (occ > 4) occ = 4;
-  if (rows >= 144 && occ > 2) occ = 2;
+  if (rows >= 128 && occ > 2) occ = 2;
   const long long slots = 256ll * occ;
   const double t_pix = (rows / 16.0) * occ * 0.0095;             // us per pixel of a round (MFMA-paced, measured ~0.7 eff)
   const double t_slab = (double)Nw * Ktot * 4.0 / 3.0e6;          // us per slab in the slab sum (vmtl_unpack_weights)
@@ -1469,7 +1471,9 @@ constexpr int wg_pm() {
          : 160 * 1024 / (2 * BP * (wg_ld(BMC, 2) + wg_ld(WG_BNK, 2)) * 4) >= base ? 2
                                                                                     : 0;
 }
-static_assert(wg_pm<144>() == 1 && wg_pm<80>() == 1 && wg_pm<36>() == 2 && wg_pm<68>() == 0 && wg_pm<20>() == 0, "wg_pm");
+static_assert(wg_pm<144>() == 1 && wg_pm<80>() == 1 && wg_pm<36>() == 2 && wg_pm<68>() == 0 && wg_pm<20>() == 0 &&
+                  wg_pm<128>() == 1,
+              "wg_pm");
 
 template <int TM, int NTR = 0>
 static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
@@ -1547,6 +1551,7 @@ static int wgrad_dispatch(WgradP& p, int splits, void* stream) {
     case 20: return launch_wgrad<1, 4>(p, splits, st);
     case 36: return launch_wgrad<2, 4>(p, splits, st);
     case 68: return launch_wgrad<4, 4>(p, splits, st);
+    case 128: return launch_wgrad<8>(p, splits, st);
     default: return launch_wgrad<9>(p, splits, st);
   }
 }
