@@ -153,15 +153,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // k-quad whose swizzled home that slot is: (l&7) ^ (row&7), row&7 == (tid>>3)&7.
   const int k4 = NS >= 2 ? ((tid & 7) ^ (r0 & 7)) : (tid & 7);
   int pixbase[RA], hb[RA], wb[RA];
+  // (b, ho, wo) of this thread's first row by two divisions, rows + 32 i by add-and-carry
+  int lb, lho, lwo;
+  {
+    const int hw = p.Ho * p.Wo, m = m0 + r0;
+    lb = m / hw;
+    const int rem = m - lb * hw;
+    lho = rem / p.Wo;
+    lwo = rem - lho * p.Wo;
+  }
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + r0 + 32 * i;
+    if (i > 0) {
+      lwo += 32;
+      while (lwo >= p.Wo) {
+        lwo -= p.Wo;
+        if (++lho == p.Ho) {
+          lho = 0;
+          ++lb;
+        }
+      }
+    }
     if (r0 + 32 * i < BM && m < p.M) {
-      const int hw = p.Ho * p.Wo;
-      const int b = m / hw;
-      const int rem = m - b * hw;
-      const int ho = rem / p.Wo;
-      const int wo = rem - ho * p.Wo;
+      const int b = lb, ho = lho, wo = lwo;
       pixbase[i] = b * p.H * p.W;
       hb[i] = UP2 ? ho - 1 + pa : ho * p.stride - p.pad;  // UP2: (Ho, Wo) are the low-res dims here
       wb[i] = UP2 ? wo - 1 + pb : wo * p.stride - p.pad;
@@ -508,11 +523,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int hw = p.Ho * p.Wo;
   // split-K: slice blockIdx.y writes its partial tile into its own slab (UP2: a slab has the full-resolution layout)
   float* yout = p.ksplit > 1 ? p.y + (size_t)blockIdx.y * (UP2 ? 4 : 1) * p.M * p.ldy : p.y;
+  // UP2: full-resolution pixel offset of each of this thread's output rows.  (b, h, w) of the thread's first row by two
+  // integer divisions, the other rows by add-and-carry: the divisions per (row, register) of round 2 were ~20 per
+  // thread = ~600 VALU instructions of an epilogue whose K loop has ~540 (the 67 -> 33 full-resolution layer runs
+  // 9 K steps per workgroup: 13.4 VALU per MFMA, tools/bench_up2.py under rocprofv3 --pmc)
+  size_t up2_off[TM][4];  // also the pixel-shuffle (ConvTranspose) scatter: pa = pb = 0 there, the (u, v) part is per column
+  if (UP2 || p.shuffle) {
+    const int mb = m0 + wm * TM * 16 + 4 * lq;
+    const int b0 = mb / hw, rem0 = mb - b0 * hw;
+    const int h0 = rem0 / p.Wo, w0 = rem0 - h0 * p.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int w_ = w0 + i * 16 + r, h_ = h0, b_ = b0;
+        while (w_ >= p.Wo) {
+          w_ -= p.Wo;
+          if (++h_ == p.Ho) {
+            h_ = 0;
+            ++b_;
+          }
+        }
+        up2_off[i][r] = ((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy;
+      }
+  }
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 16 + l15;
-    bv[j] = (p.bias != nullptr && n < p.Nw) ? p.bias[p.shuffle ? n % p.Cout : n] : 0.f;
+    // pixel shuffle: column n = (u*2+v)*Cout + co goes to pixel (2h+u, 2w+v), channel co - one division per column
+    const int shq = p.shuffle ? n / p.Cout : 0, shco = n - shq * p.Cout;
+    const size_t shuf_off = p.shuffle ? ((size_t)(shq >> 1) * (2 * p.Wo) + (shq & 1)) * p.ldy + shco : 0;
+    bv[j] = (p.bias != nullptr && n < p.Nw) ? p.bias[p.shuffle ? shco : n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -523,9 +565,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         if (UP2) {
           if (n < p.ldy) {
             if (n >= p.Cout) v = 0.f;
-            const int b_ = m / hw, rem = m - b_ * hw;
-            const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
-            yout[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
+            yout[up2_off[i][r] + n] = v;
           }
         } else if (!p.shuffle) {
           if (n < p.ldy) {
@@ -533,12 +573,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
             yout[(size_t)m * p.ldy + n] = v;
           }
         } else if (n < p.Nw) {
-          const int q = n / p.Cout, co = n - q * p.Cout;
-          const int b_ = m / hw, rem = m - b_ * hw;
-          const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
-          const size_t o =
-              ((size_t)(b_ * 2 * p.Ho + 2 * h_ + (q >> 1)) * (2 * p.Wo) + 2 * w_ + (q & 1)) * p.ldy + co;
-          p.y[o] = v;
+          p.y[up2_off[i][r] + shuf_off] = v;
         }
       }
     }
@@ -546,6 +581,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   // ---- tail columns: fold the four k quarters, lanes of quarter 0 own one output row each ----
   float tv[TM][NT > 0 ? NT : 1], txh[TM][NT > 0 ? NT : 1];
+  size_t up2_tail_off[(UP2 && NT > 0) ? TM : 1];
+  if (UP2 && NT > 0) {  // row (wm*TM + i)*16 + l15 of the tile: one division pair, + 16 rows per i by add-and-carry
+    const int mb = m0 + wm * TM * 16 + l15;
+    const int b0 = mb / hw, rem0 = mb - b0 * hw;
+    const int h0 = rem0 / p.Wo, w0 = rem0 - h0 * p.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int w_ = w0 + i * 16, h_ = h0, b_ = b0;
+      while (w_ >= p.Wo) {
+        w_ -= p.Wo;
+        if (++h_ == p.Ho) {
+          h_ = 0;
+          ++b_;
+        }
+      }
+      up2_tail_off[i] = ((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy;
+    }
+  }
   if (NT > 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -571,9 +624,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         tv[i][t] = v;
         if (lq == 0 && m < p.M && n < p.ldy) {
           if (UP2) {
-            const int b_ = m / hw, rem = m - b_ * hw;
-            const int h_ = rem / p.Wo, w_ = rem - h_ * p.Wo;
-            yout[((size_t)(b_ * 2 * p.Ho + 2 * h_ + pa) * (2 * p.Wo) + 2 * w_ + pb) * p.ldy + n] = v;
+            yout[up2_tail_off[i] + n] = v;
           } else {
             yout[(size_t)m * p.ldy + n] = v;
           }
