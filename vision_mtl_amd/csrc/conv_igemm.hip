@@ -552,8 +552,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 16 + l15;
     // pixel shuffle: column n = (u*2+v)*Cout + co goes to pixel (2h+u, 2w+v), channel co - one division per column
-    const int shq = p.shuffle ? n / p.Cout : 0, shco = n - shq * p.Cout;
-    const size_t shuf_off = p.shuffle ? ((size_t)(shq >> 1) * (2 * p.Wo) + (shq & 1)) * p.ldy + shco : 0;
+    int shco = n;
+    size_t shuf_off = 0;
+    if (p.shuffle) {  // uniform branch: plain launches pay no division here
+      const int shq = n / p.Cout;
+      shco = n - shq * p.Cout;
+      shuf_off = ((size_t)(shq >> 1) * (2 * p.Wo) + (shq & 1)) * p.ldy + shco;
+    }
     bv[j] = (p.bias != nullptr && n < p.Nw) ? p.bias[p.shuffle ? shco : n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
