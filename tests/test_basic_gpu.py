@@ -91,3 +91,39 @@ def test_build_model_errors(dev):
     with pytest.raises(RuntimeError, match="download"):
         build_model(argparse.Namespace(model_name="basic", backbone_weights="imagenet"),
                     argparse.Namespace(num_classes=3))
+
+
+def test_basic_fallback_tail_uses_the_up2_statistics_block(dev, monkeypatch):
+    """VMTL_SMALL_TAIL=0: the last decoder block's conv2 + heads through the implicit-GEMM kernels instead of the fused
+    halo-tile node.  The BatchNorm after the block's phase-decomposed conv1 must merge that launch's statistics rows
+    with ITS row block (the up2 tile picker's, carried as `_vmtl_rpb` / stats_rpb), not conv_pick_tile's: loss and
+    every gradient equal the default path's."""
+    from oracle.losses import synthetic_batch
+    from vision_mtl_amd.lit_module import MTLModule
+    from vision_mtl_amd.utils.pipeline_utils import build_model
+
+    torch.manual_seed(11)
+    model = build_model(argparse.Namespace(model_name="basic", backbone_weights=None), argparse.Namespace(num_classes=19))
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    module = MTLModule(model, num_classes=19, device=str(dev))
+    batch = {k: v.to(dev) for k, v in synthetic_batch(2, 64, 128, 19, seed=11, masked=0.1).items()}
+
+    def run():
+        model.load_state_dict(sd0)
+        for p in model.parameters():
+            p.grad = None
+        loss = module.training_step(batch, 0)
+        loss.backward()
+        return loss.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+
+    l0, g0 = run()
+    monkeypatch.setenv("VMTL_SMALL_TAIL", "0")
+    l1, g1 = run()
+    assert_close(l1, l0, tol=1e-5, what="fallback tail loss")
+    from tests.util import rel_l2
+
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:  # two fp32 summation orders of a ReLU network: the rel-L2 bar of the other end-to-end tests
+        if float(g0[k].abs().max()) > 1e-6 * gmax:
+            assert rel_l2(g1[k], g0[k]) <= 5e-2, f"fallback tail grad {k}: {rel_l2(g1[k], g0[k]):.2e}"
