@@ -32,7 +32,10 @@ LAYERS = [("blk0.c1", 32, 8, 16, 1072, 540, 3), ("blk0.c2", 32, 8, 16, 540, 540,
           # same GEMM shapes as blk2.c2 / blk3.c2 without tap re-reads (1x1): isolates the im2col operand traffic
           ("pw.blk2c2", 32, 32, 64, 1215, 135, 1), ("pw.blk3c2", 32, 64, 128, 603, 67, 1),
           # MTAN attention 1x1 convs at full resolution (bs 16, 256x256): output-heavy, 4-6 K steps
-          ("pw.mtan192", 16, 256, 256, 128, 192, 1), ("pw.mtan128", 16, 256, 256, 192, 128, 1)]
+          ("pw.mtan192", 16, 256, 256, 128, 192, 1), ("pw.mtan128", 16, 256, 256, 192, 128, 1),
+          # MTAN (bs 16, 256x256, first encoder width 32): the C -> C 3x3 convs of the four resolutions
+          ("mtan.s0", 16, 256, 256, 32, 32, 3), ("mtan.s1", 16, 128, 128, 64, 64, 3),
+          ("mtan.s2", 16, 64, 64, 128, 128, 3), ("mtan.s3", 16, 32, 32, 256, 256, 3)]
 
 
 def timeit(fn):

@@ -827,7 +827,12 @@ static_assert(wg_ld(16) == 16 && wg_ld(20) == 80 && wg_ld(144) == 144 && wg_ld(1
 // 36-row tiles ran at 36 % of the matrix pipe (wgrad M = 1 M, N = 33: 51 TF; MTAN N = 32: 56 TF), latency-bound; the
 // tall tiles (>= 80 rows: 160+ MFMAs per chunk) cover it with PD = 1 and have no registers to spare (the 68-row tile
 // would drop from 3 to 2 waves per SIMD at PD = 2: 196 VGPRs).
-template <int TM, int NTR = 0, int PM = 1, int PD = (TM <= 2 ? 3 : (TM <= 4 && NTR == 0) ? 2 : 1)>
+// FAST (host: wgrad_fast_ok): one source, Wo % BP == 0 - the BP pixels of a chunk are consecutive pixels of ONE output
+// row, so (image, row, first column) of a chunk are uniform and live in scalar registers: a gather address is
+// scalar chunk base + per-thread constant, its bounds test one add + one compare.  The general loader tracks
+// (b, ho, wo) per gather row in vector registers and rebuilds every offset with two quarter-rate multiplies: ~10
+// non-MFMA instructions per MFMA on the 32-row tile (ISA count), which is what bounded the narrow tiles.
+template <int TM, int NTR = 0, int PM = 1, int PD = (TM <= 2 ? 3 : (TM <= 4 && NTR == 0) ? 2 : 1), bool FAST = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   constexpr int TN = 2;
   constexpr int BMM = TM * 16;    // rows covered by MFMA tiles
@@ -878,14 +883,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   // adds / compares only (two integer divisions per row and chunk made this kernel VALU-issue bound:
   // 7 VALU instructions per MFMA on the narrow tiles)
   int xb[XP], xho[XP], xwo[XP];
+  if (!FAST) {
 #pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    const int m = p_begin + xr + XROWS * i;
-    const int b = m / hw;
-    const int rem = m - b * hw;
-    xb[i] = b;
-    xho[i] = rem / p.Wo;
-    xwo[i] = rem - xho[i] * p.Wo;
+    for (int i = 0; i < XP; ++i) {
+      const int m = p_begin + xr + XROWS * i;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      xb[i] = b;
+      xho[i] = rem / p.Wo;
+      xwo[i] = rem - xho[i] * p.Wo;
+    }
+  }
+  // FAST: uniform chunk position (scalar registers) + per-thread constants
+  int s_b = 0, s_ho = 0, s_wo = 0;
+  int tw[XP];          // input column of gather row i relative to the chunk's first input column
+  int toff[XP];        // byte offset of gather row i relative to the chunk's first input pixel (may be negative)
+  int tyoff[YIT];      // dY: byte offset relative to the chunk's first dY row, -1 = this lane loads nothing
+  if (FAST) {
+    s_b = p_begin / hw;
+    const int rem = p_begin - s_b * hw;
+    s_ho = rem / p.Wo;
+    s_wo = rem - s_ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      tw[i] = (xr + XROWS * i) * p.stride + dw;
+      toff[i] = ((dh * p.W + tw[i]) * p.Cs + ci) * 4;
+    }
+#pragma unroll
+    for (int it = 0; it < YIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / YQ, q = idx - row * YQ;
+      tyoff[it] = (idx < BP * YQ && co0 + q * 4 < p.ldy) ? (row * p.ldy + co0 + q * 4) * 4 : -1;
+    }
   }
 
   f32x4 ry[PD][YIT], rx[PD][XP];
@@ -900,6 +929,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   };
   // slot: compile-time index after unrolling (register arrays must not be indexed at run time)
   auto load_tile = [&](int pp, f32x4* ry_s, f32x4* rx_s) {
+    if (FAST) {
+      // every chunk is whole (M and the slice length are multiples of BP): no m < p_end test
+      const unsigned ybase = (unsigned)pp * (unsigned)p.ldy * 4u;
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) ry_s[it] = bload(rs_dy, tyoff[it] >= 0 ? ybase + (unsigned)tyoff[it] : OOB);
+      const int hin = s_ho * p.stride;  // uniform: first input row / column of the chunk (before the tap shift)
+      const int win = s_wo * p.stride;
+      const unsigned xbase = (unsigned)((s_b * p.H + hin) * p.W + win) * (unsigned)p.Cs * 4u;
+      const bool hok = xok && (unsigned)(hin + dh) < (unsigned)p.H;
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const bool ok = hok && (unsigned)(win + tw[i]) < (unsigned)p.W;
+        rx_s[i] = bload(rs_x, ok ? xbase + (unsigned)toff[i] : OOB);
+      }
+      s_wo += BP;
+      if (s_wo >= p.Wo) {
+        s_wo = 0;
+        if (++s_ho == p.Ho) {
+          s_ho = 0;
+          ++s_b;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
       const int idx = tid + it * 256;
@@ -1512,7 +1565,7 @@ static int wgrad_splits_uncached(int M, int Nw, int Ktot) {
   return (int)best;
 }
 
-template <int TM, int NTR, int PM>
+template <int TM, int NTR, int PM, bool FAST>
 static int launch_wgrad_pm(WgradP& p, int splits, hipStream_t st);
 
 // Stride rule per tile height.  Measured on MI355X (tools/bench_conv.py, VMTL_WG_PAD A/B, round 3): the conflict-free
@@ -1531,24 +1584,40 @@ static_assert(wg_pm<144>() == 1 && wg_pm<80>() == 1 && wg_pm<36>() == 2 && wg_pm
                   wg_pm<128>() == 1,
               "wg_pm");
 
-template <int TM, int NTR = 0>
-static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
-  static EnvInt e_pad{"VMTL_WG_PAD", -1};  // tuning aid: force one LDS row-stride rule (wg_ld) for every tile height
-  switch (env_int(e_pad)) {
-    case 0: return launch_wgrad_pm<TM, NTR, 0>(p, splits, st);
-    case 1: return launch_wgrad_pm<TM, NTR, 1>(p, splits, st);
-    case 2: return launch_wgrad_pm<TM, NTR, 2>(p, splits, st);
-    default: return launch_wgrad_pm<TM, NTR, wg_pm<TM * 16 + NTR>()>(p, splits, st);
-  }
+// scalar-chunk loader (conv_wgrad_kernel FAST): one source, whole chunks of one output row
+static bool wgrad_fast_ok(const WgradP& p) {
+  static EnvInt e{"VMTL_WG_FAST", 1};  // tuning aid: 0 = the general loader everywhere
+  return env_int(e) != 0 && p.x2 == nullptr && p.Wo % BP == 0 && p.chunk % BP == 0;
 }
 
-template <int TM, int NTR, int PM>
+template <int TM, int NTR = 0>
+static int launch_wgrad(WgradP& p, int splits, hipStream_t st) {
+  constexpr int PMD = wg_pm<TM * 16 + NTR>();
+#ifdef VMTL_TUNING
+  static EnvInt e_pad{"VMTL_WG_PAD", -1};  // force one LDS row-stride rule (wg_ld) for every tile height
+  switch (env_int(e_pad)) {
+    case 0: return launch_wgrad_pm<TM, NTR, 0, false>(p, splits, st);
+    case 1: return launch_wgrad_pm<TM, NTR, 1, false>(p, splits, st);
+    case 2: return launch_wgrad_pm<TM, NTR, 2, false>(p, splits, st);
+    default: break;
+  }
+#endif
+  if (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.x2 == nullptr && p.M % BP == 0) {
+    // a pointwise conv has no borders: one flat row of M pixels (so any image width takes the scalar-chunk loader)
+    p.B = 1; p.H = 1; p.W = p.M; p.Ho = 1; p.Wo = p.M;
+  }
+  if (wgrad_fast_ok(p)) return launch_wgrad_pm<TM, NTR, PMD, true>(p, splits, st);
+  return launch_wgrad_pm<TM, NTR, PMD, false>(p, splits, st);
+}
+
+template <int TM, int NTR, int PM, bool FAST>
 static int launch_wgrad_pm(WgradP& p, int splits, hipStream_t st) {
   constexpr int BMC = TM * 16 + NTR;
+  constexpr int PD = (TM <= 2 ? 3 : (TM <= 4 && NTR == 0) ? 2 : 1);
   const size_t lds = (size_t)2 * BP * (wg_ld(BMC, PM) + wg_ld(WG_BNK, PM)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, NTR, PM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TM, NTR, PM, PD, FAST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1557,7 +1626,8 @@ static int launch_wgrad_pm(WgradP& p, int splits, hipStream_t st) {
   p.tiles_kk = cdiv(p.Ktot, WG_BNK);
   p.tiles_co = cdiv(p.Nw, BMC);
   p.splits = splits;
-  hipLaunchKernelGGL((conv_wgrad_kernel<TM, NTR, PM>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, NTR, PM, PD, FAST>), dim3(p.tiles_kk * p.tiles_co * splits), dim3(256), lds, st,
+                     p);
   return vmtl_check_launch();
 }
 
