@@ -174,6 +174,49 @@ def test_conv2d_wgrad_every_row_config(dev, rows, vmtl_env):
     assert_close(wd.grad.cpu(), wr.grad, what=f"wgrad rows {rows}")
 
 
+def _wgrad_pair(dev, vmtl_env, B, Cin, H, W, Cout, K, stride, pad, seed):
+    """Weight gradient through the product path with the scalar-chunk loader (default) and with the general loader."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, stride=stride, padding=pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    got = []
+    for fast in ("1", "0"):
+        vmtl_env("VMTL_WG_FAST", fast)
+        wd = w.to(dev).requires_grad_(True)
+        y = ops.conv2d(to_dev_nhwc(x, dev), wd, None, stride=stride, pad=pad)
+        y.backward(to_dev_nhwc(gy, dev))
+        got.append(wd.grad.cpu())
+    return got, wr.grad
+
+
+@pytest.mark.parametrize("rows", [16, 32, 48, 64, 80, 144, 20, 36, 68, 128])
+def test_conv2d_wgrad_scalar_chunk_loader_every_row_config(dev, rows, vmtl_env):
+    """Output width a multiple of 32 (whole-row chunks): the scalar-chunk loader of every tile height must reproduce the
+    general loader bit for bit (same chunks, same MFMA order) and match torch; 3 images so slices cross image borders."""
+    vmtl_env("VMTL_FORCE_WG_ROWS", str(rows))
+    (fast, general), ref = _wgrad_pair(dev, vmtl_env, 3, 21, 5, 64, 70, 3, 1, 1, 900 + rows)
+    assert torch.equal(fast, general)
+    assert_close(fast, ref, what=f"wgrad rows {rows}, scalar-chunk loader")
+
+
+@pytest.mark.parametrize("case", [(2, 3, 32, 32, 64, 3, 1, 1),    # first conv of MTAN at 32x32: Cs = 4, one row per chunk
+                                  (2, 8, 16, 64, 24, 3, 2, 1),    # stride 2: Wo = 32
+                                  (2, 12, 9, 96, 19, 3, 1, 1),    # Wo = 96: three chunks per row, 20-row tile
+                                  (1, 32, 64, 128, 32, 3, 1, 1),  # Ktot = 288: the last kk tile has one live wave
+                                  (3, 16, 8, 12, 40, 1, 1, 0),    # pointwise, M = 288 = 9 chunks: the flat form
+                                  (2, 40, 7, 9, 24, 1, 1, 0)])    # pointwise, M = 126: not a multiple of 32 -> general loader
+def test_conv2d_wgrad_scalar_chunk_loader_shapes(dev, case, vmtl_env):
+    B, Cin, H, W, Cout, K, stride, pad = case
+    (fast, general), ref = _wgrad_pair(dev, vmtl_env, B, Cin, H, W, Cout, K, stride, pad, 77)
+    assert torch.equal(fast, general)
+    assert_close(fast, ref, what=f"wgrad {case}")
+
+
 @pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
 def test_conv_transpose2x2(dev, case):
     ops = _ops()

@@ -12,6 +12,7 @@ from vision_mtl_amd._lib import lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--only", default="")
+ap.add_argument("--stats", action="store_true", help="forward launches also write the BatchNorm partial rows (as in a training step)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 L = lib()
@@ -63,7 +64,11 @@ for name, B, H, W, Cin, Cout, K in LAYERS:
     dx = torch.empty(B, H, W, Cs, device=dev)
     M = B * H * W
     fl = 2.0 * M * Cout * Cin * KK
-    t_f = timeit(lambda: L.call("vmtl_conv2d_fwd", x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, B, H, W, Cs, H, W,
+    stats = None
+    if args.stats:
+        stats_t = torch.empty(L.raw("vmtl_conv2d_stats_rows")(B, H, W, ldy) + 1, 2, ldy, device=dev)
+        stats = stats_t.data_ptr()
+    t_f = timeit(lambda: L.call("vmtl_conv2d_fwd", x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), stats, B, H, W, Cs, H, W,
                                 ldy, Cout, Cout, K, K, 1, K // 2, 0, 0, st))
     t_d = timeit(lambda: L.call("vmtl_conv2d_fwd", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, H, W, ldy, H,
                                 W, Cs, Cin, Cin, K, K, 1, K // 2, 0, 0, st))

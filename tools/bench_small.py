@@ -38,7 +38,8 @@ def timeit(fn):
 
 
 tiles = L.raw("vmtl_conv3x3_small_stat_rows")(B, H, W)
-for name, Cin, Cout in [("conv2 33->33", 33, 33), ("heads 33->20", 33, 20), ("heads dgrad 20->33", 20, 33)]:
+for name, Cin, Cout in [("conv2 33->33", 33, 33), ("heads 33->20", 33, 20), ("heads dgrad 20->33", 20, 33),
+                        ("mtan 32->32", 32, 32)]:
     if args.only and args.only not in name:
         continue
     Cs, ldy = c4(Cin), c4(Cout)
