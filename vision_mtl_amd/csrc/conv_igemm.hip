@@ -112,7 +112,11 @@ __device__ __forceinline__ void split3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3)
 }
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool UP2 = false, int NT = 0, int NS = 0, int X3 = 0>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+// The 128x160 tile took 264 registers: ONE wave per SIMD, nothing to overlap its loads with.  Its second launch bound asks
+// for two (<= 256 registers: 216-238, no spills): 13-18 % faster on the 145..160-column layers (tools/bench_conv.py dgrad
+// blk1-3.c1: 465 -> 405, 501 -> 426, 590 -> 484 us).  Only that tile: the same bound on every instantiation made the
+// narrow ones use MORE registers (the allocator stops economising once two waves fit) and cost the step 0.07 ms.
+__global__ __launch_bounds__(256, (TM * TN >= 20 && WAVES_N == 2) ? 2 : 1) void conv_igemm_kernel(ConvP p) {
   constexpr int BM = WAVES_M * TM * 16;
   constexpr int BNM = WAVES_N * TN * 16;  // columns covered by MFMA tiles
   constexpr int BN = BNM + NT;            // + tail columns
