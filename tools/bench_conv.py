@@ -72,6 +72,13 @@ for name, B, H, W, Cin, Cout, K in LAYERS:
                                 ldy, Cout, Cout, K, K, 1, K // 2, 0, 0, st))
     t_d = timeit(lambda: L.call("vmtl_conv2d_fwd", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, H, W, ldy, H,
                                 W, Cs, Cin, Cin, K, K, 1, K // 2, 0, 0, st))
+    # the data gradient with the producer's BatchNorm + ReLU backward in its epilogue (vmtl_conv2d_bnbwd)
+    ezs = torch.empty(L.raw("vmtl_conv2d_stats_rows")(B, H, W, Cs) + 1, 2, Cs, device=dev)
+    ezx = torch.randn(B, H, W, Cs, device=dev)
+    vec = [torch.rand(Cs, device=dev) + 0.5 for _ in range(4)]
+    t_z = timeit(lambda: L.call("vmtl_conv2d_bnbwd", dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), ezs.data_ptr(), ezx.data_ptr(),
+                                vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), 1, B, H, W, ldy, H,
+                                W, Cs, Cin, Cin, K, K, 1, K // 2, st))
     S = L.raw("vmtl_conv2d_wgrad_splits")(M, Cout, KK * Cs)
     slabs = torch.empty(S, Cout, KK * Cs, device=dev)
     t_w = timeit(lambda: L.call("vmtl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), S, B, H, W, Cs, H, W, ldy,
@@ -81,6 +88,6 @@ for name, B, H, W, Cin, Cout, K in LAYERS:
     tot["wgrad"] += t_w
     flops += fl
     print(f"{name:8s} M={M:8d} Cin={Cin:5d} Cout={Cout:4d}  fwd {t_f * 1e3:7.1f} us {fl / t_f / 1e9:6.1f} TF | "
-          f"dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF | wgrad(S={S:3d}) {t_w * 1e3:7.1f} us {fl / t_w / 1e9:6.1f} TF")
+          f"dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF (+bnbwd {t_z * 1e3:6.1f}) | wgrad(S={S:3d}) {t_w * 1e3:7.1f} us {fl / t_w / 1e9:6.1f} TF")
 print(f"TOTAL fwd {tot['fwd']:.3f} ms ({flops / tot['fwd'] / 1e9:.1f} TF)  dgrad {tot['dgrad']:.3f} ms ({flops / tot['dgrad'] / 1e9:.1f} TF)"
       f"  wgrad {tot['wgrad']:.3f} ms ({flops / tot['wgrad'] / 1e9:.1f} TF)  sum {sum(tot.values()):.3f} ms")
