@@ -93,7 +93,7 @@ def time_conv_kernels(module, batch, reps=3):
             lib().callk(name, stream=stream, **kw)
         e1.record()
         e1.synchronize()
-        if name == "vmtl_conv1x1_cat_wgrad":
+        if name in ("vmtl_conv1x1_cat_wgrad", "vmtl_conv3x3_wgrad_small"):
             name = "vmtl_conv2d_wgrad"
         f = fam[name if name in ("vmtl_conv2d_wgrad", "vmtl_stitch") else "vmtl_conv2d_fwd"]
         ms = e0.elapsed_time(e1) / reps

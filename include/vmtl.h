@@ -133,6 +133,17 @@ int vmtl_conv2d_wgrad_splits(int M, int Nw, int Ktot);
 int vmtl_conv2d_wgrad(const float* x, const float* dy, float* slabs, int splits, int B, int H, int W, int Cs,
                       int Ho, int Wo, int ldy, int Nw, int KH, int KW, int stride, int pad, void* stream);
 
+/* Weight gradient of a NARROW 3x3 / stride 1 / pad 1 conv on a strip-walking halo kernel (csrc/conv_wgrad_small.hip): x is read
+ * from memory once instead of once per tap.  Replaces the same conv2d backward-weight call sites of the reference as
+ * vmtl_conv2d_wgrad (reference models: smp DecoderBlock / SegmentationHead convs, utils/model_utils.py:61-80 DoubleConv) where
+ * supported(Cs, ldy, W) says so: Cs, ldy <= 36 (multiples of 4), W a multiple of 32.  slabs: [vmtl_conv3x3_wgrad_small_slabs(B, H, W)]
+ * [Nw][9*Cs], summed by vmtl_unpack_weights(..., nslabs) exactly like the slabs of vmtl_conv2d_wgrad. */
+int vmtl_conv3x3_wgrad_small_supported(int Cs, int ldy, int W);
+int vmtl_conv3x3_wgrad_small_slabs(int B, int H, int W);
+int vmtl_conv3x3_wgrad_small(const float* x, const float* dy, float* slabs, int nslabs, int B, int H, int W, int Cs,
+                             int ldy, int Nw, void* stream);
+
+
 /* 3x3 / stride 1 / pad 1 conv for the narrow full-resolution layers (Cs in {16,20,32,36} storage channels in,
  * Nw <= 36 rows of the packed [Nw][9*Cs] weight out): the last decoder block and the heads of `basic`
  * (models/basic_model.py:30-51; smp DecoderBlock conv2 via utils/model_utils.py:25-34) and their data gradients.

@@ -217,6 +217,44 @@ def test_conv2d_wgrad_scalar_chunk_loader_shapes(dev, case, vmtl_env):
     assert_close(fast, ref, what=f"wgrad {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 16, 64, 32),   # MTAN's 32 -> 32: 18 kk tiles, 2 co tiles
+                                  (2, 33, 9, 32, 30),    # Cs = 36 (kk tiles straddle taps, 21 of them), one strip
+                                  (1, 33, 70, 96, 20),   # heads: ldy = 20; 70 rows: several bands with a ragged last one
+                                  (3, 16, 12, 64, 16),   # csnet
+                                  (2, 32, 12, 64, 16),
+                                  (2, 16, 10, 32, 1),    # depth head: one output channel
+                                  (2, 3, 40, 64, 24),    # first conv: Cs = 4, 3 kk tiles
+                                  (1, 20, 5, 128, 36)])   # 3 co tiles
+def test_conv3x3_wgrad_small(dev, case, vmtl_env):
+    """The strip-walking halo weight gradient against torch and against conv_wgrad_kernel (VMTL_WGRAD_SMALL=0), through the
+    product path (ops.conv2d backward) and directly through the C ABI with the band geometry forced small."""
+    from vision_mtl_amd._lib import lib
+
+    ops = _ops()
+    B, Cin, H, W, Cout = case
+    Cs, ldy = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    assert lib().raw("vmtl_conv3x3_wgrad_small_supported")(Cs, ldy, W) == 1
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    got = {}
+    for mode, target in (("small", None), ("small_bands", 4096), ("general", None)):
+        vmtl_env("VMTL_WGRAD_SMALL", "0" if mode == "general" else "1")
+        if target:
+            vmtl_env("VMTL_WS_TARGET", str(target))  # many short strip segments: every band boundary / halo row is exercised
+        wd = w.to(dev).requires_grad_(True)
+        y = ops.conv2d(to_dev_nhwc(x, dev), wd, None, stride=1, pad=1)
+        y.backward(to_dev_nhwc(gy, dev))
+        got[mode] = wd.grad.cpu()
+    for mode in ("small", "small_bands", "general"):
+        assert_close(got[mode], wr.grad, what=f"wgrad {mode} {case}")
+    assert not torch.equal(got["small"], got["general"]) or Cout * Cin < 64  # different kernels (summation orders) really ran
+
+
 @pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
 def test_conv_transpose2x2(dev, case):
     ops = _ops()

@@ -36,7 +36,10 @@ LAYERS = [("blk0.c1", 32, 8, 16, 1072, 540, 3), ("blk0.c2", 32, 8, 16, 540, 540,
           ("pw.mtan192", 16, 256, 256, 128, 192, 1), ("pw.mtan128", 16, 256, 256, 192, 128, 1),
           # MTAN (bs 16, 256x256, first encoder width 32): the C -> C 3x3 convs of the four resolutions
           ("mtan.s0", 16, 256, 256, 32, 32, 3), ("mtan.s1", 16, 128, 128, 64, 64, 3),
-          ("mtan.s2", 16, 64, 64, 128, 128, 3), ("mtan.s3", 16, 32, 32, 256, 256, 3)]
+          ("mtan.s2", 16, 64, 64, 128, 128, 3), ("mtan.s3", 16, 32, 32, 256, 256, 3),
+          # csnet's full-resolution decoder tail (bs 32, 128x256) and MTAN's first conv
+          ("cs.32-16", 32, 128, 256, 32, 16, 3), ("cs.16-16", 32, 128, 256, 16, 16, 3), ("cs.16-19", 32, 128, 256, 16, 19, 3),
+          ("cs.16-1", 32, 128, 256, 16, 1, 3), ("cs.80-32", 32, 64, 128, 80, 32, 3), ("mtan.c0", 16, 256, 256, 3, 32, 3)]
 
 
 def timeit(fn):
@@ -83,11 +86,18 @@ for name, B, H, W, Cin, Cout, K in LAYERS:
     slabs = torch.empty(S, Cout, KK * Cs, device=dev)
     t_w = timeit(lambda: L.call("vmtl_conv2d_wgrad", x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), S, B, H, W, Cs, H, W, ldy,
                                 Cout, K, K, 1, K // 2, st))
+    t_ws = None
+    if K == 3 and L.raw("vmtl_conv3x3_wgrad_small_supported")(Cs, ldy, W):  # the strip-walking halo kernel on the same layer
+        ns = L.raw("vmtl_conv3x3_wgrad_small_slabs")(B, H, W)
+        slabs_s = torch.empty(ns, Cout, KK * Cs, device=dev)
+        t_ws = timeit(lambda: L.call("vmtl_conv3x3_wgrad_small", x.data_ptr(), dy.data_ptr(), slabs_s.data_ptr(), ns, B, H, W, Cs,
+                                     ldy, Cout, st))
     tot["fwd"] += t_f
     tot["dgrad"] += t_d
     tot["wgrad"] += t_w
     flops += fl
     print(f"{name:8s} M={M:8d} Cin={Cin:5d} Cout={Cout:4d}  fwd {t_f * 1e3:7.1f} us {fl / t_f / 1e9:6.1f} TF | "
-          f"dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF (+bnbwd {t_z * 1e3:6.1f}) | wgrad(S={S:3d}) {t_w * 1e3:7.1f} us {fl / t_w / 1e9:6.1f} TF")
+          f"dgrad {t_d * 1e3:7.1f} us {fl / t_d / 1e9:6.1f} TF (+bnbwd {t_z * 1e3:6.1f}) | wgrad(S={S:3d}) {t_w * 1e3:7.1f} us {fl / t_w / 1e9:6.1f} TF"
+          + (f" | halo wgrad {t_ws * 1e3:7.1f} us {fl / t_ws / 1e9:6.1f} TF" if t_ws else ""))
 print(f"TOTAL fwd {tot['fwd']:.3f} ms ({flops / tot['fwd'] / 1e9:.1f} TF)  dgrad {tot['dgrad']:.3f} ms ({flops / tot['dgrad'] / 1e9:.1f} TF)"
       f"  wgrad {tot['wgrad']:.3f} ms ({flops / tot['wgrad'] / 1e9:.1f} TF)  sum {sum(tot.values()):.3f} ms")

@@ -15,6 +15,7 @@ d, cmd = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 stats_csv = sys.argv[3] if len(sys.argv) > 3 else None
 bench_line = sys.argv[4] if len(sys.argv) > 4 else None
 FAM = [("conv_igemm_kernel", "conv_igemm_kernel"), ("conv_wgrad_kernel", "conv_wgrad_kernel"),
+       ("wgrad_small_kernel", "wgrad_small_kernel"),
        ("conv3x3_small_kernel", "conv3x3_small_kernel"), ("pw_gemm_kernel", "pw_gemm_kernel"), ("pw_big_kernel", "pw_big_kernel"),
        ("stitch", "stitch_kernel"),
        ("bn_", "bn_* (BatchNorm family)"), ("dwconv", "dwconv_*"), ("pack", "pack / unpack"), ("at::native", "ATen"),
@@ -71,7 +72,7 @@ if stats_csv and bench_line:
         f = family(r["Name"])
         fam_ms[f] = fam_ms.get(f, 0.0) + float(r["TotalDurationNs"]) * 1e-6
         fam_calls[f] = fam_calls.get(f, 0) + int(r["Calls"])
-    conv_fams = ("conv_igemm_kernel", "conv_wgrad_kernel", "conv3x3_small_kernel", "pw_gemm_kernel", "pw_big_kernel", "stitch_kernel")
+    conv_fams = ("conv_igemm_kernel", "conv_wgrad_kernel", "wgrad_small_kernel", "conv3x3_small_kernel", "pw_gemm_kernel", "pw_big_kernel", "stitch_kernel")
     per_step = {f: (ms / (steps + replays) if f in conv_fams else ms / max(steps, 1)) for f, ms in fam_ms.items()}
     trace = {"source": "rocprofv3 --kernel-trace --stats of the same configuration (VMTL_SIDE_STREAM=0: isolated durations)",
              "step_executions": steps, "conv_replays_per_launch": replays,
@@ -86,10 +87,11 @@ if stats_csv and bench_line:
                                               "achieved_tflops": round(tf, 2), "frac_of_157.3": round(tf / 157.3, 4),
                                               "bench_line_frac_unprofiled": rf.get("frac")}
         wg = rf.get("wgrad_kernel")
-        if wg and per_step.get("conv_wgrad_kernel"):
+        wms = per_step.get("conv_wgrad_kernel", 0.0) + per_step.get("wgrad_small_kernel", 0.0)  # both weight-gradient kernels
+        if wg and wms:
             wflop = wg["achieved"] * 1e12 * wg["ms_per_step_in_kernel"] * 1e-3
-            wtf = wflop / (per_step["conv_wgrad_kernel"] * 1e-3) / 1e12
-            trace["conv_wgrad_recomputed"] = {"ms_per_step_in_kernel": round(per_step["conv_wgrad_kernel"], 3),
+            wtf = wflop / (wms * 1e-3) / 1e12
+            trace["conv_wgrad_recomputed"] = {"ms_per_step_in_kernel": round(wms, 3),
                                               "achieved_tflops": round(wtf, 2), "frac_of_157.3": round(wtf / 157.3, 4),
                                               "bench_line_frac_unprofiled": wg.get("frac")}
     res["kernel_trace"] = trace

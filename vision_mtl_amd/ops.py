@@ -431,6 +431,14 @@ def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None, 
 
 def _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Nw, KH, KW, stride, pad, flop, xflop=None):
     """Weight-gradient slabs [splits][Nw][KH*KW*Cs] (summed later by unpack)."""
+    if (KH == 3 and KW == 3 and stride == 1 and pad == 1
+            and lib().raw("vmtl_conv3x3_wgrad_small_supported")(Cs, ldy, W)):
+        # narrow full-resolution layers: the strip-walking halo kernel reads x once instead of once per tap
+        ns = lib().raw("vmtl_conv3x3_wgrad_small_slabs")(B, H, W)
+        slabs = _empty((ns, Nw, 9 * Cs), x)
+        _k("vmtl_conv3x3_wgrad_small", _flop=flop, _xflop=xflop, x=x, dy=dy, slabs=slabs, nslabs=ns, B=B, H=H, W=W, Cs=Cs, ldy=ldy,
+           Nw=Nw)
+        return slabs, ns
     splits = lib().raw("vmtl_conv2d_wgrad_splits")(B * Ho * Wo, Nw, KH * KW * Cs)
     slabs = _empty((splits, Nw, KH * KW * Cs), x)
     _k("vmtl_conv2d_wgrad", _flop=flop, _xflop=xflop, x=x, dy=dy, slabs=slabs, splits=splits, B=B, H=H, W=W, Cs=Cs, Ho=Ho, Wo=Wo,
