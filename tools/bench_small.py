@@ -39,7 +39,8 @@ def timeit(fn):
 
 tiles = L.raw("vmtl_conv3x3_small_stat_rows")(B, H, W)
 for name, Cin, Cout in [("conv2 33->33", 33, 33), ("heads 33->20", 33, 20), ("heads dgrad 20->33", 20, 33),
-                        ("mtan 32->32", 32, 32)]:
+                        ("mtan 32->32", 32, 32), ("cs 32->16", 32, 16), ("cs 16->32", 16, 32), ("cs 16->16", 16, 16),
+                        ("cs 16->19", 16, 19), ("cs 16->1", 16, 1)]:
     if args.only and args.only not in name:
         continue
     Cs, ldy = c4(Cin), c4(Cout)
