@@ -255,6 +255,51 @@ def test_conv3x3_wgrad_small(dev, case, vmtl_env):
     assert not torch.equal(got["small"], got["general"]) or Cout * Cin < 64  # different kernels (summation orders) really ran
 
 
+@pytest.mark.parametrize("case", [(2, 16, 8, 32, 16, False), (2, 32, 12, 64, 16, False), (1, 16, 9, 40, 32, True),
+                                  (2, 16, 8, 32, 19, True), (2, 16, 6, 36, 1, True), (1, 33, 8, 64, 33, True),
+                                  (2, 32, 8, 32, 32, False)])
+def test_plain_narrow_conv_on_the_halo_tile_kernel(dev, case, monkeypatch):
+    """Launches without a statistics epilogue of narrow 3x3 layers (data gradients, heads) are routed to
+    vmtl_conv3x3_small above _SMALL_MIN_ROWS pixels: forced here at test sizes, forward (+ bias) and data gradient vs torch."""
+    ops = _ops()
+    recorded = []
+    orig_k = ops._k
+
+    def spy(name, *a, **kw):
+        recorded.append(name)
+        return orig_k(name, *a, **kw)
+
+    monkeypatch.setattr(ops, "_SMALL_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "_k", spy)
+    B, Cin, H, W, Cout, bias = case
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    y = ops.conv2d(xd, wd, bd, stride=1, pad=1)  # no statistics requested
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="conv fwd (halo-tile kernel)")
+    if y.shape[-1] > Cout:
+        assert y[..., Cout:].abs().max().item() == 0.0
+    y.backward(to_dev_nhwc(gy, dev))
+    # forward: the input's channel storage must be one of the kernel's widths; data gradient: dy's
+    want = sum(((c + 3) // 4 * 4) in (16, 20, 32, 36) for c in (Cin, Cout))
+    assert recorded.count("vmtl_conv3x3_small") == want and want >= 1, recorded
+    assert_close(from_dev_nhwc(xd.grad, Cin), xr.grad, what="conv dgrad (halo-tile kernel)")
+    if xd.grad.shape[-1] > Cin:
+        assert xd.grad[..., Cin:].abs().max().item() == 0.0
+    assert_close(wd.grad.cpu(), wr.grad, what="conv wgrad")
+    if bias:
+        assert_close(bd.grad.cpu(), br.grad, what="conv bias grad")
+
+
 @pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
 def test_conv_transpose2x2(dev, case):
     ops = _ops()
