@@ -52,25 +52,36 @@ struct PackDesc {
   int sstride, smode;
 };
 
+// One thread per packed element.  The element -> descriptor search runs over a copy of the table's `start` column in LDS
+// (it ran over global memory: 7 dependent loads per element, and the index arithmetic was 64-bit - the launch took 125 us
+// for ~3 M elements at the head of every step, in front of the first conv); offsets inside one operand fit 32 bits.
+#define PACK_MAXD 1024
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int n, long long total) {
+  __shared__ long long starts[PACK_MAXD];
+  const bool in_lds = n <= PACK_MAXD;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < n; k += 256) starts[k] = descs[k].start;
+    __syncthreads();
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = n - 1;  // last descriptor with start <= i
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (descs[mid].start <= i) lo = mid;
+      if ((in_lds ? starts[mid] : descs[mid].start) <= i) lo = mid;
       else hi = mid - 1;
     }
     const PackDesc d = descs[lo];
-    const long long j = i - d.start;
-    const int c = (int)(j % d.Cs);
-    long long rest = j / d.Cs;
-    const int tp = (int)(rest % d.T);
-    rest /= d.T;
-    const int r0 = (int)(rest % d.R0);
-    const int r1 = (int)(rest / d.R0);
+    const unsigned j = (unsigned)(i - d.start);  // < R1*R0*T*Cs < 2^31 (host check)
+    const unsigned Cs = (unsigned)d.Cs, T = (unsigned)d.T, R0 = (unsigned)d.R0;
+    unsigned rest = j / Cs;
+    const int c = (int)(j - rest * Cs);
+    const unsigned q1 = rest / T;
+    const int tp = (int)(rest - q1 * T);
+    const unsigned r1 = q1 / R0;
+    const int r0 = (int)(q1 - r1 * R0);
     const int t = d.flip ? d.T - 1 - tp : tp;
-    float v = c < d.C ? d.src[r1 * d.sr1 + r0 * d.sr0 + t * d.st + c * d.sc] : 0.f;
+    float v = c < d.C ? d.src[(long long)r1 * d.sr1 + r0 * d.sr0 + t * d.st + c * d.sc] : 0.f;
     if (d.smode != 0 && c < d.C) v *= d.scale[(size_t)(d.smode == 1 ? c : r0) * d.sstride];
     d.dst[j] = v;
   }

@@ -335,6 +335,8 @@ class _PackCache:
             recs, start = [], 0
             for e in live:
                 R1, R0, T, C, Cs, sr1, sr0, st, sc, flip = e["params"]
+                if R1 * R0 * T * Cs >= 1 << 31:
+                    raise ValueError("packed operand too large for the batched pack kernel (32-bit offsets inside one operand)")
                 sptr, sstride, smode = e.get("scale", (0, 0, 0))
                 recs.append(struct.pack("<QQqqqqqQiiiiiiii", e["ptr"] + 4 * e.get("offset", 0), e["dst"].data_ptr(), sr1, sr0,
                                         st, sc, start, sptr, R1, R0, T, C, Cs, flip, sstride, smode))
