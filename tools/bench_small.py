@@ -63,6 +63,7 @@ for name, Cin, Cout in [("conv2 33->33", 33, 33), ("heads 33->20", 33, 20), ("he
 
     ez = dict(ez_x=xz, ez_mean=vec[0], ez_invstd=vec[1], ez_gamma=vec[2], ez_beta=vec[3])
     variants = [("plain", small()),
+                ("stats only (mode 1)", small(stats=stats, ep_mode=1)),
                 ("prologue relu + a_out", small(pa=pa, pc=pc, act_in=1, a_out=a_out)),
                 ("prologue + stats (mode 1)", small(pa=pa, pc=pc, act_in=1, a_out=a_out, stats=stats, ep_mode=1)),
                 ("mode 2 (BN bwd epilogue)", small(stats=stats, ep_mode=2, **ez)),
@@ -74,3 +75,8 @@ for name, Cin, Cout in [("conv2 33->33", 33, 33), ("heads 33->20", 33, 20), ("he
                          ldy=ldy, Nw=Cout, Cout=Cout, KH=3, KW=3, stride=1, pad=1, act=0, shuffle=0, stream=st)
     us = timeit(ig)
     print(f"igemm  {name:20s} {'plain':34s} {us:8.1f} us  {flop / us / 1e6:6.1f} TF", flush=True)
+    st_ig = torch.empty(L.raw("vmtl_conv2d_stats_rows")(B, H, W, ldy) + 1, 2, ldy, device=dev)
+    igs = lambda: L.callk("vmtl_conv2d_fwd", x=x, wp=wp, bias=None, y=y, stats=st_ig, B=B, H=H, W=W, Cs=Cs, Ho=H, Wo=W,
+                          ldy=ldy, Nw=Cout, Cout=Cout, KH=3, KW=3, stride=1, pad=1, act=0, shuffle=0, stream=st)
+    us = timeit(igs)
+    print(f"igemm  {name:20s} {'with the statistics epilogue':34s} {us:8.1f} us  {flop / us / 1e6:6.1f} TF", flush=True)
