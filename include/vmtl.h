@@ -255,6 +255,18 @@ int vmtl_bn_bwd_finalize(const float* partial, int nblk, int M, int C, int Cs, f
 int vmtl_bn_bwd_apply(const float* x, const float* dz, const float* mean, const float* invstd, const float* gamma,
                       const float* sum_dz, const float* sum_dzx, float* dx, int M, int C, int Cs, int training,
                       void* stream);
+
+/* BatchNorm + activation + MaxPool2d(2) as ONE node (csrc/bn.hip): reference models/mtan_model.py:67-83 (AttentionModuleEncoder:
+ * conv3 -> bn3 -> ReLU -> max_pool2d, nobody else reads the full-resolution activation).  fwd: y [B][H/2][W/2][Cs] from x
+ * [B][H][W][Cs] (H, W even) with mean / invstd from vmtl_bn_stats; bwd: the pooled gradient dyp is scattered to each window's
+ * arg-max inside the BatchNorm reduce / apply sweeps (sum_dz, sum_dzx [C] = dbeta, dgamma; partial:
+ * vmtl_reduce_rows(B*(H/2)*(W/2))*2*Cs floats). */
+int vmtl_bn_act_pool2_fwd(const float* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float* y, int B, int H, int W, int C, int Cs, int act, void* stream);
+int vmtl_bn_act_pool2_bwd(const float* x, const float* dyp, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float* partial, float* sum_dz, float* sum_dzx,
+                          float* dx, int B, int H, int W, int C, int Cs, int act, int training, void* stream);
+
 /* out[c] = sum_m a[m][c] (mode 0) or a*b (mode 1); reduce_all sums over channels too.
  * partial: (vmtl_reduce_rows(M) + 1) * Cs floats of scratch */
 int vmtl_colsum(const float* a, const float* b, int M, int C, int Cs, int mode, int reduce_all,

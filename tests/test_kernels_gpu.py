@@ -558,6 +558,52 @@ def test_bn_large_mean_small_std(dev, fused):
     assert_close(from_dev_nhwc(z.grad, C), zr.grad, tol=5e-3, what="bn(large mean) dz")
 
 
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(2, 33, 8, 12), (3, 64, 6, 10), (1, 128, 2, 2)])
+def test_bn_act_pool2_fused(dev, shape, training):
+    """BatchNorm + ReLU + MaxPool2d(2) as one node (MTAN's encoder attention tail) against the three torch modules: values,
+    dx, dgamma, dbeta, running buffers - and against the two separate nodes of this library (VMTL_FUSE_BN_POOL=0 path)."""
+    ops = _ops()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)  # some negative scales: the arg-max is taken AFTER the BatchNorm
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn.train(training)
+    sd = {k: v.clone() for k, v in bn.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(F.relu(bn(xr)), 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    def run(fused):
+        bd = torch.nn.BatchNorm2d(C)
+        bd.load_state_dict(sd)
+        bd = bd.to(dev).train(training)
+        xd = to_dev_nhwc(x, dev).requires_grad_(True)
+        args = (xd, bd.weight, bd.bias, bd.running_mean, bd.running_var, bd.num_batches_tracked, C, training, 0.1, bd.eps,
+                ops.ACT_RELU)
+        y = ops.bn_act_pool2(*args) if fused else ops.maxpool2(ops.bn_act(*args))
+        y.backward(to_dev_nhwc(gy, dev))
+        return y, xd.grad, bd
+    y, dx, bd = run(True)
+    assert_close(from_dev_nhwc(y, C), yr.detach(), what="bn+relu+pool fwd")
+    if y.shape[-1] > C:
+        assert y[..., C:].abs().max().item() == 0.0 and dx[..., C:].abs().max().item() == 0.0
+    assert_close(from_dev_nhwc(dx, C), xr.grad, what="bn+relu+pool dx")
+    assert_close(bd.weight.grad.cpu(), bn.weight.grad, what="dgamma")
+    assert_close(bd.bias.grad.cpu(), bn.bias.grad, what="dbeta")
+    assert_close(bd.running_mean.cpu(), bn.running_mean, tol=1e-5, what="running_mean")
+    assert_close(bd.running_var.cpu(), bn.running_var, tol=1e-5, what="running_var")
+    y2, dx2, bd2 = run(False)
+    assert_close(y.cpu(), y2.cpu(), tol=1e-6, what="fused vs separate nodes")
+    assert_close(dx.cpu(), dx2.cpu(), tol=1e-5, what="fused vs separate nodes dx")
+
+
 def test_plain_activation(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(5)

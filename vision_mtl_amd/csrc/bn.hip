@@ -637,6 +637,181 @@ extern "C" int vmtl_bn_bwd_apply(const float* x, const float* dz, const float* m
   return vmtl_check_launch();
 }
 
+// ---------------------------------------------------------------- BatchNorm + activation + 2x2 max-pool in one pass
+// MTAN's encoder attention modules end in conv3 -> BatchNorm -> ReLU -> MaxPool2d(2) (reference models/mtan_model.py:67-83) and
+// nobody else reads the full-resolution activation.  Forward: one sweep of x writes only the pooled map (the separate passes
+// wrote and re-read the full-resolution activation).  Backward: the pooled gradient is scattered to the window's arg-max ON THE
+// FLY (first maximum in window order, NaN wins - the rule of maxpool2_bwd_kernel) inside the BatchNorm reduce and apply
+// sweeps; the full-resolution gradient of the pool never exists.  A "row" of the sweep skeletons is one pooled pixel.
+struct PoolRow {
+  f32x4 v[4], g;
+  size_t o00;
+};
+
+__device__ __forceinline__ size_t pool_window(int r, int q, int H, int W, int Cs) {
+  const int Wo = W >> 1, Ho = H >> 1;
+  const int wo = r % Wo, t = r / Wo;
+  const int ho = t % Ho, b = t / Ho;
+  return ((size_t)(b * H + 2 * ho) * W + 2 * wo) * Cs + (size_t)q * 4;
+}
+
+__device__ __forceinline__ void pool_load(PoolRow& l, const float* x, int r, int q, int H, int W, int Cs) {
+  l.o00 = pool_window(r, q, H, W, Cs);
+  l.v[0] = *reinterpret_cast<const f32x4*>(x + l.o00);
+  l.v[1] = *reinterpret_cast<const f32x4*>(x + l.o00 + Cs);
+  l.v[2] = *reinterpret_cast<const f32x4*>(x + l.o00 + (size_t)W * Cs);
+  l.v[3] = *reinterpret_cast<const f32x4*>(x + l.o00 + (size_t)W * Cs + Cs);
+}
+
+// activation values, normalised inputs and arg-max of one window element e of the quad
+template <int ACT>
+__device__ __forceinline__ int pool_argmax(const PoolRow& l, const BnBwdCoef& k, int e, float* xh, float* z, float& amax) {
+  int am = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    xh[w] = (l.v[w][e] - k.mean[e]) * k.invstd[e];
+    z[w] = k.gamma[e] * xh[w] + k.beta[e];
+    const float a = act_fwd(z[w], ACT);
+    if (w == 0) amax = a;
+    else if (a > amax || a != a) { amax = a; am = w; }
+  }
+  return am;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void bn_act_pool2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                                       int Mp, int H, int W, int C, int Cs) {
+  column_sweep2(
+      Mp, Cs >> 2, [&](int q) { return bn_bwd_coef(q, C, mean, invstd, gamma, beta, nullptr, nullptr, 0.f); },
+      [&](int r, int q) {
+        PoolRow l;
+        pool_load(l, x, r, q, H, W, Cs);
+        return l;
+      },
+      [&](const PoolRow& l, int r, int q, const BnBwdCoef& k) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh[4], z[4], amax;
+          pool_argmax<ACT>(l, k, e, xh, z, amax);
+          o[e] = k.valid[e] != 0.f ? amax : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + (size_t)r * Cs + (size_t)q * 4) = o;
+      });
+}
+
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void bn_pool2_bwd_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dyp, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, int Mp, int H, int W,
+    int C, int Cs, float* partial) {
+  column_reduce_init2<2>(
+      Mp, Cs >> 2, Cs, partial, [&](int q) { return bn_bwd_coef(q, C, mean, invstd, gamma, beta, nullptr, nullptr, 0.f); },
+      [&](int r, int q) {
+        PoolRow l;
+        pool_load(l, x, r, q, H, W, Cs);
+        l.g = *reinterpret_cast<const f32x4*>(dyp + (size_t)r * Cs + (size_t)q * 4);
+        return l;
+      },
+      [&](const PoolRow& l, int r, int q, const BnBwdCoef& k, f32x4* acc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh[4], z[4], amax;
+          const int am = pool_argmax<ACT>(l, k, e, xh, z, amax);
+          const float dz = k.valid[e] * l.g[e] * act_grad(z[am], ACT);
+          acc[0][e] += dz;
+          acc[1][e] += dz * xh[am];
+        }
+      });
+}
+
+template <int ACT>
+__global__ __launch_bounds__(RED_THREADS) void bn_pool2_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dyp, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, float* __restrict__ dx, int Mp, int H, int W, int C,
+    int Cs, int training) {
+  const float invM = 1.f / (4.f * (float)Mp);  // the BatchNorm saw all four pixels of every window
+  const bool use_sums = training != 0;
+  column_sweep2(
+      Mp, Cs >> 2,
+      [&](int q) {
+        return bn_bwd_coef(q, C, mean, invstd, gamma, beta, use_sums ? sum_dz : nullptr, use_sums ? sum_dzx : nullptr, invM);
+      },
+      [&](int r, int q) {
+        PoolRow l;
+        pool_load(l, x, r, q, H, W, Cs);
+        l.g = *reinterpret_cast<const f32x4*>(dyp + (size_t)r * Cs + (size_t)q * 4);
+        return l;
+      },
+      [&](const PoolRow& l, int r, int q, const BnBwdCoef& k) {
+        f32x4 d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xh[4], z[4], amax;
+          const int am = pool_argmax<ACT>(l, k, e, xh, z, amax);
+          const float dz = k.valid[e] * l.g[e] * act_grad(z[am], ACT);
+          const float gi = k.gamma[e] * k.invstd[e];
+#pragma unroll
+          for (int w = 0; w < 4; ++w) d[w][e] = k.valid[e] * gi * ((w == am ? dz : 0.f) - k.c1[e] - xh[w] * k.c2[e]);
+        }
+        *reinterpret_cast<f32x4*>(dx + l.o00) = d[0];
+        *reinterpret_cast<f32x4*>(dx + l.o00 + Cs) = d[1];
+        *reinterpret_cast<f32x4*>(dx + l.o00 + (size_t)W * Cs) = d[2];
+        *reinterpret_cast<f32x4*>(dx + l.o00 + (size_t)W * Cs + Cs) = d[3];
+      });
+}
+
+// y [B][H/2][W/2][Cs] = maxpool2(act(BN(x))), x [B][H][W][Cs] (H, W even); mean / invstd from vmtl_bn_stats
+extern "C" int vmtl_bn_act_pool2_fwd(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, float* y, int B, int H, int W, int C, int Cs, int act, void* stream) {
+  VMTL_ENTER();
+  if (!x || !y || !mean || !invstd || B <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || C <= 0 || C > Cs || (Cs & 3))
+    return VMTL_ERR_ARG;
+  if ((long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
+  const int Mp = B * (H >> 1) * (W >> 1);
+  const int nb = sweep_blocks(Mp, Cs);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(A)                                                                                                        \
+  hipLaunchKernelGGL((bn_act_pool2_fwd_kernel<A>), dim3(nb), dim3(RED_THREADS), 0, st, x, mean, invstd, gamma, beta, y, Mp, H, \
+                     W, C, Cs)
+  VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
+  return vmtl_check_launch();
+}
+
+// backward of the above: dyp [B][H/2][W/2][Cs] -> dx [B][H][W][Cs], sum_dz / sum_dzx [C] = the BatchNorm's bias / weight
+// gradients; partial: vmtl_reduce_rows(B*(H/2)*(W/2)) * 2 * Cs floats
+extern "C" int vmtl_bn_act_pool2_bwd(const float* x, const float* dyp, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, float* partial, float* sum_dz, float* sum_dzx,
+                                     float* dx, int B, int H, int W, int C, int Cs, int act, int training, void* stream) {
+  VMTL_ENTER();
+  if (!x || !dyp || !dx || !mean || !invstd || !partial || !sum_dz || !sum_dzx || B <= 0 || H < 2 || W < 2 || (H & 1) ||
+      (W & 1) || C <= 0 || C > Cs || (Cs & 3))
+    return VMTL_ERR_ARG;
+  if ((long long)B * H * W > 0x7fffffffLL) return VMTL_ERR_ARG;
+  const int Mp = B * (H >> 1) * (W >> 1);
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = red_blocks(Mp);
+#define CALL(A)                                                                                                            \
+  hipLaunchKernelGGL((bn_pool2_bwd_reduce_kernel<A>), dim3(nblk), dim3(RED_THREADS), 0, st, x, dyp, mean, invstd, gamma, beta, \
+                     Mp, H, W, C, Cs, partial)
+  VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) >> 2), dim3(256), 0, st, partial, nblk, C, Cs, sum_dz, sum_dzx,
+                     nullptr, nullptr, nullptr, 0.f, 0, nullptr, nullptr, nullptr);
+  const int nb = sweep_blocks(Mp, Cs);
+#define CALL(A)                                                                                                           \
+  hipLaunchKernelGGL((bn_pool2_bwd_apply_kernel<A>), dim3(nb), dim3(RED_THREADS), 0, st, x, dyp, mean, invstd, gamma, beta, \
+                     sum_dz, sum_dzx, dx, Mp, H, W, C, Cs, training)
+  VMTL_ACT_SWITCH(act, CALL)
+#undef CALL
+  return vmtl_check_launch();
+}
+
 // ---------------------------------------------------------------- generic column sums
 // out[k][c] = sum_m f_k(a[m][c], b[m][c]);  mode 0: (a) -> bias gradient, mode 1: (a*b) -> stitch/scale gradient
 __global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const float* __restrict__ a,

@@ -120,6 +120,20 @@ def bn_act(x: Act, bn: nn.BatchNorm2d, act: int, mul: Act | None = None, res: Ac
     return Act(y, x.C)
 
 
+def conv_bn_act_maxpool2(x: Act, c: nn.Conv2d, bn: nn.BatchNorm2d, act: int) -> Act:
+    """maxpool2(act(BN(conv(x)))) with the BatchNorm + activation + pool as ONE node (ops.bn_act_pool2): for a dense conv
+    whose full-resolution activation nobody else reads."""
+    if c.groups != 1:
+        raise ValueError("conv_bn_act_maxpool2 expects a dense conv")
+    train = bn.training
+    out = ops.conv2d(x.t, c.weight, c.bias, _pair(c.stride), _pair(c.padding), want_stats=train,
+                     zero_bias_grad=train and c.bias is not None)
+    y, stats = out if train else (out, None)
+    p = ops.bn_act_pool2(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, c.out_channels,
+                         bn.training, _momentum(bn), bn.eps, act, stats=stats)
+    return Act(p, c.out_channels)
+
+
 def activation(x: Act, act: int) -> Act:
     return Act(ops.activation(x.t, act, x.C), x.C)
 

@@ -59,7 +59,7 @@ class AttentionModuleEncoder(_Attention):
             assert prev_layer_outs is not None, "prev_layer_outs must be provided for non-first AttentionModuleEncoder"
             merged = (conv1_shared, prev_layer_outs)  # read by conv1 as two sources: no concat pass
         g = self._mask_and_gate(merged, conv2_shared)
-        return L.maxpool2(L.conv_bn_act(g, self.conv3, self.bn3, ACT_RELU))
+        return L.conv_bn_act_maxpool2(g, self.conv3, self.bn3, ACT_RELU)  # bn3 + ReLU + MaxPool2d: one node
 
 
 class AttentionModuleDecoder(_Attention):

@@ -1437,6 +1437,68 @@ def bn_act(x, gamma, beta, running_mean, running_var, nbt, C, training, momentum
                         act, stats_rpb)
 
 
+class _BNActPool(torch.autograd.Function):
+    """maxpool2(act(BN(x))) as one node: the full-resolution activation and the full-resolution gradient of the pool never exist
+    (vmtl_bn_act_pool2_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, stats, C, training, momentum, eps, act, stats_rpb):
+        x = _req(x, "x")
+        B, H, W, Cs = x.shape
+        M = B * H * W
+        mean, invstd = _empty((Cs,), x), _empty((Cs,), x)
+        if training:
+            if stats is not None:
+                partial, nblk = stats, stats.shape[0]
+                rpb = stats_rpb if stats_rpb else lib().raw("vmtl_conv2d_stats_block")(B, H, W, Cs)
+            else:
+                partial, nblk, rpb = _empty((_reduce_rows(M), 2, Cs), x), 0, 0
+            _k("vmtl_bn_stats", x=x, M=M, C=C, Cs=Cs, partial=partial, nblk_from_conv=nblk, rows_per_blk_from_conv=rpb,
+               eps=eps, momentum=momentum, running_mean=running_mean, running_var=running_var, num_batches_tracked=nbt,
+               save_mean=mean, save_invstd=invstd)
+        else:
+            _k("vmtl_bn_eval_stats", running_mean=running_mean, running_var=running_var, C=C, Cs=Cs, eps=eps,
+               save_mean=mean, save_invstd=invstd)
+        y = _empty((B, H // 2, W // 2, Cs), x)
+        _k("vmtl_bn_act_pool2_fwd", x=x, mean=mean, invstd=invstd, gamma=gamma, beta=beta, y=y, B=B, H=H, W=W, C=C, Cs=Cs,
+           act=act)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.cfg = (C, training, act)
+        ctx.slots = (_slot(gamma), _slot(beta))
+        return y
+
+    @staticmethod
+    def backward(ctx, dyp):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        C, training, act = ctx.cfg
+        dyp = _req(dyp, "dy")
+        B, H, W, Cs = x.shape
+        partial = _empty((_reduce_rows(B * (H // 2) * (W // 2)), 2, Cs), x)
+        sum_dzx = _empty((C,), x) if ctx.slots[0] is None else ctx.slots[0]  # exactly C entries: may be arena slots
+        sum_dz = _empty((C,), x) if ctx.slots[1] is None else ctx.slots[1]
+        dx = _empty(x.shape, x)
+        _k("vmtl_bn_act_pool2_bwd", x=x, dyp=dyp, mean=mean, invstd=invstd, gamma=gamma, beta=beta, partial=partial,
+           sum_dz=sum_dz, sum_dzx=sum_dzx, dx=dx, B=B, H=H, W=W, C=C, Cs=Cs, act=act, training=1 if training else 0)
+        dgamma = sum_dzx if ctx.slots[0] is None else None
+        dbeta = sum_dz if ctx.slots[1] is None else None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+FUSE_BN_POOL = os.environ.get("VMTL_FUSE_BN_POOL", "1") != "0"  # MTAN encoder attention: BN + ReLU + MaxPool2d as one node
+
+
+def bn_act_pool2(x, gamma, beta, running_mean, running_var, nbt, C, training, momentum=0.1, eps=1e-5, act=ACT_NONE,
+                 stats=None, stats_rpb=0):
+    """maxpool2(act(BN(x))); falls back to the two separate nodes for odd extents (MaxPool2d floors) or when switched off."""
+    B, H, W, Cs = x.shape
+    if stats is not None and not stats_rpb:
+        stats_rpb = getattr(stats, "_vmtl_rpb", 0)
+    if not FUSE_BN_POOL or (H & 1) or (W & 1) or H < 2 or W < 2:
+        return maxpool2(bn_act(x, gamma, beta, running_mean, running_var, nbt, C, training, momentum, eps, act, stats=stats,
+                               stats_rpb=stats_rpb))
+    return _BNActPool.apply(x, gamma, beta, running_mean, running_var, nbt, stats, C, training, momentum, eps, act, stats_rpb)
+
+
 def activation(x, act, C, mul=None):
     """Plain activation (optionally times a gate operand) through the same fused kernel."""
     return _BNAct.apply(x, None, None, None, None, None, mul, None, None, C, False, 0.0, 0.0, act, 0)
