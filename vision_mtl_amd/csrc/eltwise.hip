@@ -25,6 +25,30 @@ static inline int ew_grid(long long total, int per_block = 256) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total);     \
        i += (long long)gridDim.x * blockDim.x)
 
+// (channel quad, column, row, image) of flat float4 index i over a [B][H][W][CQ] map.  The decode is the bulk of the VALU work of
+// these streaming kernels: with 64-bit operands each division is ~100 instructions (bilinear x2 ran at 2.8 TB/s); every map of
+// this library has fewer than 2^31 float4 elements, so the 32-bit form is the one that runs (uniform switch).
+struct Pix4 { int q, w, h, b; };
+__device__ __forceinline__ Pix4 decode_pix(long long i, int CQ, int W, int H, bool small) {
+  Pix4 p;
+  if (small) {
+    const unsigned u = (unsigned)i, pix = u / (unsigned)CQ;
+    p.q = (int)(u - pix * (unsigned)CQ);
+    const unsigned t = pix / (unsigned)W;
+    p.w = (int)(pix - t * (unsigned)W);
+    const unsigned b = t / (unsigned)H;
+    p.h = (int)(t - b * (unsigned)H);
+    p.b = (int)b;
+  } else {
+    p.q = (int)(i % CQ);
+    const long long pix = i / CQ;
+    p.w = (int)(pix % W);
+    p.h = (int)((pix / W) % H);
+    p.b = (int)(pix / ((long long)W * H));
+  }
+  return p;
+}
+
 // ------------------------------------------------------------------ concat2
 struct CatSrc {
   const float* p;  // [B][Hs][Ws][Cs]
@@ -144,9 +168,8 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
                                                        int H, int W, int Cs, long long total4) {
   const int CQ = Cs >> 2, Ho = H >> 1, Wo = W >> 1;
   GRID_STRIDE(i, total4) {
-    const int q = (int)(i % CQ);
-    const long long pix = i / CQ;
-    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+    const Pix4 px = decode_pix(i, CQ, Wo, Ho, total4 < (1ll << 31));
+    const int q = px.q, wo = px.w, ho = px.h, b = px.b;
     const float* base = x + ((size_t)(b * H + 2 * ho) * W + 2 * wo) * Cs + (size_t)q * 4;
     f32x4 m = *reinterpret_cast<const f32x4*>(base);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + Cs);
@@ -168,9 +191,8 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
   // one thread per OUTPUT pixel quad: recompute the argmax, write all four input gradients
   const int CQ = Cs >> 2, Ho = H >> 1, Wo = W >> 1;
   GRID_STRIDE(i, total4) {
-    const int q = (int)(i % CQ);
-    const long long pix = i / CQ;
-    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+    const Pix4 px = decode_pix(i, CQ, Wo, Ho, total4 < (1ll << 31));
+    const int q = px.q, wo = px.w, ho = px.h, b = px.b;
     const size_t o00 = ((size_t)(b * H + 2 * ho) * W + 2 * wo) * Cs + (size_t)q * 4;
     const size_t o01 = o00 + Cs, o10 = o00 + (size_t)W * Cs, o11 = o10 + Cs;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o00);
@@ -232,10 +254,10 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const float* __restri
                                                            int H, int W, int Cs, float sh, float sw,
                                                            long long total4) {
   const int CQ = Cs >> 2, Ho = 2 * H, Wo = 2 * W;
+  const bool small = total4 < (1ll << 31);
   GRID_STRIDE(i, total4) {
-    const int q = (int)(i % CQ);
-    const long long pix = i / CQ;
-    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+    const Pix4 px = decode_pix(i, CQ, Wo, Ho, small);
+    const int q = px.q, wo = px.w, ho = px.h, b = px.b;
     int h0, h1, w0, w1;
     float lh, lw;
     bil_coord(ho, H, sh, h0, h1, lh);
@@ -256,16 +278,19 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* __re
                                                                int B, int H, int W, int Cs, float sh, float sw,
                                                                long long total4) {
   const int CQ = Cs >> 2, Ho = 2 * H, Wo = 2 * W;
+  const bool small = total4 < (1ll << 31);
+  // reciprocal scales once per thread (the candidate ranges below carry a margin of one pixel on each side, which absorbs the
+  // rounding difference to a true division; every candidate is re-tested exactly with bil_coord)
+  const float ish = 1.f / fmaxf(sh, 1e-20f), isw = 1.f / fmaxf(sw, 1e-20f);
   GRID_STRIDE(i, total4) {
-    const int q = (int)(i % CQ);
-    const long long pix = i / CQ;
-    const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    const Pix4 px = decode_pix(i, CQ, W, H, small);
+    const int q = px.q, w = px.w, h = px.h, b = px.b;
     // candidate output rows: those with floor(sh*ho) in {h-1, h} (clamped in float: sh may be 0)
     const float fHo = (float)(Ho - 1), fWo = (float)(Wo - 1);
-    int ho_lo = h > 0 ? (int)fminf(floorf((float)(h - 1) / fmaxf(sh, 1e-20f)), fHo) - 1 : 0;
-    int ho_hi = (int)fminf(ceilf((float)(h + 1) / fmaxf(sh, 1e-20f)) + 1.f, fHo);
-    int wo_lo = w > 0 ? (int)fminf(floorf((float)(w - 1) / fmaxf(sw, 1e-20f)), fWo) - 1 : 0;
-    int wo_hi = (int)fminf(ceilf((float)(w + 1) / fmaxf(sw, 1e-20f)) + 1.f, fWo);
+    int ho_lo = h > 0 ? (int)fminf(floorf((float)(h - 1) * ish), fHo) - 1 : 0;
+    int ho_hi = (int)fminf(ceilf((float)(h + 1) * ish) + 1.f, fHo);
+    int wo_lo = w > 0 ? (int)fminf(floorf((float)(w - 1) * isw), fWo) - 1 : 0;
+    int wo_hi = (int)fminf(ceilf((float)(w + 1) * isw) + 1.f, fWo);
     ho_lo = max(ho_lo, 0); wo_lo = max(wo_lo, 0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* base = dy + (size_t)b * Ho * Wo * Cs + (size_t)q * 4;
