@@ -300,6 +300,43 @@ def test_plain_narrow_conv_on_the_halo_tile_kernel(dev, case, monkeypatch):
         assert_close(bd.grad.cpu(), br.grad, what="conv bias grad")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 8, 32, 32, True), (2, 16, 12, 64, 16, False), (1, 32, 8, 64, 16, False),
+                                  (2, 16, 8, 32, 19, True)])
+def test_narrow_conv_with_statistics_on_the_halo_tile_kernel(dev, case, monkeypatch):
+    """Narrow 3x3 launches WITH the BatchNorm statistics epilogue (and a bias, as MTAN's attention convs have) on
+    vmtl_conv3x3_small: values, the (mean, M2) partial rows under the geometry ops.conv_stats_geometry reports, gradients."""
+    ops = _ops()
+    recorded = []
+    orig_k = ops._k
+    monkeypatch.setattr(ops, "_SMALL_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "_k", lambda name, *a, **kw: (recorded.append(name), orig_k(name, *a, **kw))[1])
+    B, Cin, H, W, Cout, bias = case
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = to_dev_nhwc(x, dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    y, stats = ops.conv2d(xd, wd, None if b is None else b.to(dev), stride=1, pad=1, want_stats=True)
+    assert "vmtl_conv3x3_small" in recorded and "vmtl_conv2d_fwd" not in recorded
+    assert_close(from_dev_nhwc(y, Cout), yr.detach(), what="conv fwd")
+    M, rpb = B * H * W, stats._vmtl_rpb
+    assert stats.shape[0] * rpb == M
+    st = stats.double().cpu()
+    mean = st[:, 0].mean(0)
+    var = (st[:, 1] + rpb * (st[:, 0] - mean) ** 2).sum(0) / M
+    yo = yr.detach().double()
+    assert_close(mean[:Cout], yo.mean((0, 2, 3)), tol=1e-5, atol=1e-6, what="stats mean")
+    assert_close(var[:Cout], yo.var((0, 2, 3), unbiased=False), tol=1e-4, what="stats var")
+    y.backward(to_dev_nhwc(gy, dev))
+    assert_close(from_dev_nhwc(xd.grad, Cin), xr.grad, what="conv dgrad")
+    assert_close(wd.grad.cpu(), wr.grad, what="conv wgrad")
+
+
 @pytest.mark.parametrize("case", [(2, 64, 5, 7, 32, True), (1, 512, 4, 4, 256, True), (3, 8, 3, 3, 5, False)])
 def test_conv_transpose2x2(dev, case):
     ops = _ops()

@@ -73,7 +73,8 @@ extern "C" int vmtl_conv3x3_small(const float* x, const float* x2, const float* 
   if (act_in != VMTL_ACT_NONE && act_in != VMTL_ACT_RELU) return VMTL_ERR_ARG;
   if (ep_mode < 0 || ep_mode > 2 || (ep_mode != 0 && (!stats || (H % CSM_TH) || (W % CSM_TW)))) return VMTL_ERR_ARG;
   if (ep_mode == 2 && (!ez_x || !ez_mean || !ez_invstd || !ez_gamma || !ez_beta)) return VMTL_ERR_ARG;
-  if (ep_mode != 0 && (bias != nullptr || yb != nullptr)) return VMTL_ERR_ARG;
+  // (mode 1 + bias is fine: the bias is added before the statistics are taken, as BatchNorm(conv(x) + b) needs)
+  if ((ep_mode == 2 && bias != nullptr) || (ep_mode != 0 && yb != nullptr)) return VMTL_ERR_ARG;
   if (yb != nullptr && (Ca <= 0 || Ca >= Cout || (W & 3))) return VMTL_ERR_ARG;
   if ((long long)B * H * W * 36 > 0x7fffffffLL) return VMTL_ERR_UNSUPPORTED;  // 32-bit element offsets in the kernel
   SmallP p;

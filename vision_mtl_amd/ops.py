@@ -509,8 +509,24 @@ def conv_ksplit(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad, shuffle=0) -> int:
     return lib().raw("vmtl_conv2d_ksplit")(B, Ho, Wo, ldy, KH * KW * Cs)
 
 
+_SMALL_STATS = os.environ.get("VMTL_SMALL_STATS", "1") != "0"  # statistics-epilogue launches of narrow layers there too
+
+
+def _small_route(B, H, W, Cs, ldy, KH, KW, stride, pad, shuffle=0, with_stats=False) -> bool:
+    """A narrow full-resolution 3x3 / stride 1 / pad 1 launch that runs on the halo-tile kernel (vmtl_conv3x3_small) instead
+    of the implicit GEMM: 11-20 % faster on 16/32-channel layers at 1 M pixels (tools/bench_small.py), with or without the
+    statistics epilogue (whose tiles must be whole: H % 4 == 0, W % 32 == 0)."""
+    if shuffle or KH != 3 or KW != 3 or stride != 1 or pad != 1 or ldy > 36 or B * H * W < _SMALL_MIN_ROWS:
+        return False
+    if not conv3x3_small_supported(Cs, ldy):  # weight rows <= ldy
+        return False
+    return not with_stats or (_SMALL_STATS and H % 4 == 0 and W % 32 == 0)
+
+
 def conv_stats_geometry(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad):
     """(rows, pixels per row) of the BatchNorm partial rows a conv launch of this shape emits from its epilogue."""
+    if _small_route(B, Ho, Wo, Cs, ldy, KH, KW, stride, pad, with_stats=True):
+        return lib().raw("vmtl_conv3x3_small_stat_rows")(B, Ho, Wo), lib().raw("vmtl_conv3x3_small_stat_block")(B, Ho, Wo)
     if _is_pw(B, Ho, Wo, KH, KW, stride, pad):
         M = B * Ho * Wo
         return lib().raw("vmtl_conv1x1_stats_rows")(M, ldy, Cs, 0), lib().raw("vmtl_conv1x1_stats_block")(M, ldy, Cs, 0)
@@ -524,11 +540,10 @@ def _conv_launch(x, wp, bias, y, stats, B, H, W, Cs, Ho, Wo, ldy, Nw, Cout, KH, 
         _k("vmtl_conv1x1_fwd", _flop=flop if algo_flop is None else algo_flop, _xflop=flop, x=x, wp=wp, bias=bias, y=y,
            stats=stats, M=B * Ho * Wo, Ks=Cs, ldy=ldy, Nw=Nw, Cout=Cout)
         return
-    if (stats is None and not shuffle and KH == 3 and KW == 3 and stride == 1 and pad == 1 and ldy <= 36
-            and B * H * W >= _SMALL_MIN_ROWS and conv3x3_small_supported(Cs, Nw)):
-        # narrow full-resolution layer without a statistics epilogue (data gradients, the heads): the halo-tile kernel reads
-        # the input once; 14-18 % faster than the implicit GEMM on 16/32-channel layers at 1 M pixels (tools/bench_small.py)
-        _small(x, wp, y, B, H, W, Cs, ldy, Nw, Cout, flop if algo_flop is None else algo_flop, bias=bias)
+    if _small_route(B, H, W, Cs, ldy, KH, KW, stride, pad, shuffle, with_stats=stats is not None):
+        # narrow full-resolution layer: the halo-tile kernel reads the input once (statistics rows: conv_stats_geometry)
+        _small(x, wp, y, B, H, W, Cs, ldy, Nw, Cout, flop if algo_flop is None else algo_flop, bias=bias, stats=stats,
+               ep_mode=1 if stats is not None else 0)
         return
     if stats is None and not shuffle:
         # contraction without a statistics epilogue (data gradients; forward convs of tile-starved layers, see
@@ -1032,8 +1047,8 @@ class _BNActConv(torch.autograd.Function):
             wp = packs.get(weight, "fwd", (1, Cout, 9, Cin, Cs, 0, Cin * 9, 1, 9, 0))
             y = _empty((B, H, W, ldy), x)
             if want_stats and conv_ksplit(B, H, W, Cs, ldy, 3, 3, 1, 1) == 1:
-                ostats = _empty((lib().raw("vmtl_conv2d_stats_rows")(B, H, W, ldy), 2, ldy), x)
-                orpb = lib().raw("vmtl_conv2d_stats_block")(B, H, W, ldy)
+                rows, orpb = conv_stats_geometry(B, H, W, Cs, ldy, 3, 3, 1, 1)
+                ostats = _empty((rows, 2, ldy), x)
             _conv_launch(a, wp, None, y, ostats, B, H, W, Cs, H, W, ldy, Cout, Cout, 3, 3, 1, 1, cin=Cin)
         ctx.save_for_backward(x, a, skip, weight, mean, invstd, gamma, beta)
         ctx.cfg = (C, training, act, up2)
@@ -1077,10 +1092,17 @@ class _BNActConv(torch.autograd.Function):
             and os.environ.get("VMTL_BNBWD_FUSE", "1") != "0"
         if fuse:
             dz = _empty(x.shape, x)
-            rows = lib().raw("vmtl_conv2d_stats_rows")(B, H, W, Cs)
-            part = _empty((rows, 2, Cs), x)
-            _k("vmtl_conv2d_bnbwd", _flop=flop, _xflop=xflop, x=dy, wp=wd, y=dz, stats=part, ez_x=x, ez_mean=mean,
-               ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, **geo)
+            if not up2 and _small_route(B, H, W, ldy, Cs, 3, 3, 1, 1, with_stats=True):
+                # narrow layer: the same fused data gradient on the halo-tile kernel (ep_mode 2)
+                rows = lib().raw("vmtl_conv3x3_small_stat_rows")(B, H, W)
+                part = _empty((rows, 2, Cs), x)
+                _small(dy, wd, dz, B, H, W, ldy, Cs, Cin, Cin, flop, stats=part, ep_mode=2,
+                       ez=(x, mean, invstd, gamma, beta, act))
+            else:
+                rows = lib().raw("vmtl_conv2d_stats_rows")(B, H, W, Cs)
+                part = _empty((rows, 2, Cs), x)
+                _k("vmtl_conv2d_bnbwd", _flop=flop, _xflop=xflop, x=dy, wp=wd, y=dz, stats=part, ez_x=x, ez_mean=mean,
+                   ez_invstd=invstd, ez_gamma=gamma, ez_beta=beta, ez_act=act, **geo)
             _k("vmtl_bn_bwd_finalize", partial=part, nblk=rows, M=M, C=C, Cs=Cs, sum_dz=dbeta, sum_dzx=dgamma, mean=None,
                invstd=None, gamma=None, training=1 if training else 0, coef_a=None, coef_b=None, coef_c=None)
             if dx is not None:
@@ -1133,7 +1155,7 @@ def bn_act_conv(x, stats, rpb, bn, C, act, weight, skip=None, up2=False, want_st
         B, H, W, _ = x.shape
         ldy = y.shape[3]
         orpb = (lib().raw("vmtl_conv2d_up2_stats_block")(B, H, W, ldy) if up2
-                else lib().raw("vmtl_conv2d_stats_block")(B, H, W, ldy))
+                else conv_stats_geometry(B, H, W, x.shape[3], ldy, 3, 3, 1, 1)[1])
     return y, ostats, orpb
 
 
