@@ -433,7 +433,7 @@ def unpack(packed, shape, R1, R0, T, C, Cs, sr1, sr0, st, sc, flip=0, out=None, 
 
 def _wgrad(x, dy, B, H, W, Cs, Ho, Wo, ldy, Nw, KH, KW, stride, pad, flop, xflop=None):
     """Weight-gradient slabs [splits][Nw][KH*KW*Cs] (summed later by unpack)."""
-    if (KH == 3 and KW == 3 and stride == 1 and pad == 1
+    if (KH == 3 and KW == 3 and stride == 1 and pad == 1 and B * H * W * max(Cs, ldy) * 4 < 1 << 32
             and lib().raw("vmtl_conv3x3_wgrad_small_supported")(Cs, ldy, W)):
         # narrow full-resolution layers: the strip-walking halo kernel reads x once instead of once per tap
         ns = lib().raw("vmtl_conv3x3_wgrad_small_slabs")(B, H, W)
@@ -517,6 +517,8 @@ def _small_route(B, H, W, Cs, ldy, KH, KW, stride, pad, shuffle=0, with_stats=Fa
     of the implicit GEMM: 11-20 % faster on 16/32-channel layers at 1 M pixels (tools/bench_small.py), with or without the
     statistics epilogue (whose tiles must be whole: H % 4 == 0, W % 32 == 0)."""
     if shuffle or KH != 3 or KW != 3 or stride != 1 or pad != 1 or ldy > 36 or B * H * W < _SMALL_MIN_ROWS:
+        return False
+    if B * H * W * 36 > 0x7FFFFFFF:  # that kernel's 32-bit element offsets
         return False
     if not conv3x3_small_supported(Cs, ldy):  # weight rows <= ldy
         return False
